@@ -1,0 +1,178 @@
+// host_cabi.cpp — extern "C" surface of librt_host.so (declared in include/rt_host.h).
+#include <cstring>
+#include <memory>
+#include <new>
+
+#include "../../include/rt_host.h"
+#include "png_write.hpp"
+#include "scene.hpp"
+
+using rtm::vec3;
+
+struct rth_scene {
+    ModelLoader loader;
+    std::unique_ptr<QTable> qtable;
+    std::unique_ptr<BVHContainer> bvh;
+    std::vector<float> zero16 = std::vector<float>(4, 0.0f);
+};
+
+// Tracer::updateRays, reference src/Tracer.cpp:110-130; Camera, reference src/Camera.cpp:9-17.
+void rt_update_rays(const vec3 &eye, const vec3 &lookAt, const vec3 &up, float fov, float x, float y, float zn,
+                    float zf, rtm::vec4 out[4]) {
+    const rtm::mat4 view = rtm::lookAt(eye, lookAt, up);
+    const rtm::mat4 persp = rtm::perspective(rtm::radians(fov), x / y, zn, zf);
+    rtm::mat4 m = persp * view;
+    m = rtm::transpose(rtm::inverse(m));
+    const float corners[4][2] = {{-1, -1}, {-1, +1}, {+1, -1}, {+1, +1}};
+    for (int k = 0; k < 4; ++k) {
+        rtm::vec4 r = rtm::vec4(corners[k][0], corners[k][1], 0, 1) * m;
+        r = r / r.w;
+        r = r - rtm::vec4(eye, 0.0f);
+        out[k] = r;
+    }
+}
+
+extern "C" {
+
+rth_scene *rth_scene_load_obj(const char *path) {
+    if (!path) return nullptr;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return nullptr;
+    std::fclose(f);
+    rth_scene *s = new (std::nothrow) rth_scene;
+    if (!s) return nullptr;
+    s->loader.loadObj(path);
+    return s;
+}
+
+rth_scene *rth_scene_new(void) { return new (std::nothrow) rth_scene; }
+
+int rth_scene_add_triangles(rth_scene *s, const void *records, size_t n) {
+    if (!s || (!records && n)) return -1;
+    if (s->bvh) return -2;
+    const GPUTriangle *g = static_cast<const GPUTriangle *>(records);
+    for (size_t i = 0; i < n; ++i) {
+        Triangle t;
+        for (int a = 0; a < 3; ++a) {
+            t.vertices[0][a] = g[i].v0[a];
+            t.vertices[1][a] = g[i].v1[a];
+            t.vertices[2][a] = g[i].v2[a];
+            t.normals[0][a] = g[i].n0[a];
+            t.normals[1][a] = g[i].n1[a];
+            t.normals[2][a] = g[i].n2[a];
+        }
+        t.uvs[0] = rtm::vec2(g[i].uv0[0], g[i].uv0[1]);
+        t.uvs[1] = rtm::vec2(g[i].uv1[0], g[i].uv1[1]);
+        t.uvs[2] = rtm::vec2(g[i].uv2[0], g[i].uv2[1]);
+        t.objId = g[i].objId < 0 ? 0 : g[i].objId;
+        int m = g[i].mtlIndex;
+        if (m < 0 || m >= (int)s->loader.materialsVector.size()) m = s->loader.defaultMaterialIndex();
+        t.materialIndex = m;
+        s->loader.addTriangle(t);
+    }
+    return 0;
+}
+
+int rth_scene_add_material(rth_scene *s, const float Kd[3], float Ns, const float Ke[3]) {
+    if (!s || !Kd || !Ke) return -1;
+    Material m;
+    m.Kd = vec3(Kd[0], Kd[1], Kd[2]);
+    m.Ke = vec3(Ke[0], Ke[1], Ke[2]);
+    m.Ns = Ns;
+    m.emitter = (Ke[0] > 0.0f || Ke[1] > 0.0f || Ke[2] > 0.0f);
+    return s->loader.addMaterial(m, "");
+}
+
+int rth_scene_add_quad_light(rth_scene *s, const float c[3], float hx, float hz, const float Ke[3]) {
+    if (!s || !c || !Ke) return -1;
+    if (s->bvh) return -2;
+    s->loader.addQuadLight(vec3(c[0], c[1], c[2]), hx, hz, vec3(Ke[0], Ke[1], Ke[2]));
+    return 0;
+}
+
+int rth_scene_build(rth_scene *s, int with_qtable, uint32_t qtable_seed) {
+    if (!s) return -1;
+    if (s->loader.triangles.empty()) return -3;
+    s->qtable.reset(new QTable(with_qtable ? s->loader.numObjs : 0));
+    s->qtable->seed = qtable_seed;
+    if (with_qtable) s->qtable->makeVoronoi(s->loader.triangles_per_obj);
+    s->bvh.reset(new BVHContainer(s->loader.triangles, s->loader.materialsVector, s->loader.emitters,
+                                  s->qtable->normal_per_voronoi, s->qtable->voronoi_centres));
+    return 0;
+}
+
+int rth_scene_get_info(const rth_scene *s, rth_scene_info *out) {
+    if (!s || !out) return -1;
+    std::memset(out, 0, sizeof(*out));
+    out->num_triangles = (int32_t)s->loader.triangles.size();
+    out->num_materials = (int32_t)s->loader.materialsVector.size();
+    out->num_emitters = (int32_t)s->loader.emitters.size();
+    out->num_objects = s->loader.numObjs;
+    if (s->bvh) {
+        out->num_nodes = (int32_t)s->bvh->nodesBuffer.size();
+        out->max_leaf_triangles = s->bvh->maxLeafTriangles;
+        out->depth = s->bvh->depth;
+    }
+    vec3 lo, hi;
+    s->loader.bounds(lo, hi);
+    for (int a = 0; a < 3; ++a) {
+        out->bbox_min[a] = lo[a];
+        out->bbox_max[a] = hi[a];
+    }
+    return 0;
+}
+
+int rth_scene_buffer(const rth_scene *s, int slot, const void **bytes, size_t *nbytes) {
+    if (!s || !bytes || !nbytes) return -1;
+    if (!s->bvh) return -2;
+    const BVHContainer &b = *s->bvh;
+    const void *p = nullptr;
+    size_t n = 0;
+    switch (slot) {
+    case RTH_SLOT_NODES: p = b.nodesBuffer.data(); n = b.nodesBuffer.size() * sizeof(GPUNode); break;
+    case RTH_SLOT_TRIANGLES: p = b.trianglesBuffer.data(); n = b.trianglesBuffer.size() * sizeof(GPUTriangle); break;
+    case RTH_SLOT_MATERIALS: p = b.mtlBuffer.data(); n = b.mtlBuffer.size() * sizeof(GPUMaterial); break;
+    case RTH_SLOT_EMITTERS: p = b.emittersBuffer.data(); n = b.emittersBuffer.size() * sizeof(GPUTriangle); break;
+    case RTH_SLOT_VORONOI_NORMALS: p = b.normalsVoronoiBuffer.data(); n = b.normalsVoronoiBuffer.size() * 4; break;
+    case RTH_SLOT_VORONOI_CENTRES: p = b.voronoiCentresBuffer.data(); n = b.voronoiCentresBuffer.size() * 4; break;
+    case RTH_SLOT_QTABLE: p = s->qtable->QTableBuffer.data(); n = s->qtable->QTableBuffer.size() * 4; break;
+    case RTH_SLOT_QVISITS: p = s->qtable->QVisitsBuffer.data(); n = s->qtable->QVisitsBuffer.size() * 4; break;
+    default: return -4;
+    }
+    *bytes = p;
+    *nbytes = n;
+    return 0;
+}
+
+int rth_scene_triangle_order(const rth_scene *s, const uint32_t **order, size_t *n) {
+    if (!s || !order || !n) return -1;
+    if (!s->bvh) return -2;
+    *order = s->bvh->triangleOrder.data();
+    *n = s->bvh->triangleOrder.size();
+    return 0;
+}
+
+void rth_scene_free(rth_scene *s) { delete s; }
+
+int rth_camera_rays(const float eye[3], const float look_at[3], const float up[3], float fov_deg, float width,
+                    float height, float z_near, float z_far, float out_rays[12]) {
+    if (!eye || !look_at || !up || !out_rays) return -1;
+    rtm::vec4 r[4];
+    rt_update_rays(vec3(eye[0], eye[1], eye[2]), vec3(look_at[0], look_at[1], look_at[2]), vec3(up[0], up[1], up[2]),
+                   fov_deg, width, height, z_near, z_far, r);
+    for (int k = 0; k < 4; ++k) {
+        out_rays[3 * k + 0] = r[k].x;
+        out_rays[3 * k + 1] = r[k].y;
+        out_rays[3 * k + 2] = r[k].z;
+    }
+    return 0;
+}
+
+int rth_write_png(const char *path, int width, int height, const uint8_t *rgba, int flip) {
+    if (!path) return -1;
+    return rt_write_png_rgba(path, width, height, rgba, flip != 0);
+}
+
+const char *rth_version(void) { return "raytracer_amd host 0.1 (round 1)"; }
+
+} // extern "C"
