@@ -1,0 +1,132 @@
+"""TEST INFRASTRUCTURE — ctypes binding of oracle/librt_oracle.so (CPU restatement, rt_oracle.h).
+May be imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librt_oracle.so")
+
+
+class OrcScene(ctypes.Structure):
+    _fields_ = [("nodes", ctypes.c_void_p), ("num_nodes", ctypes.c_int32),
+                ("triangles", ctypes.c_void_p), ("num_triangles", ctypes.c_int32),
+                ("materials", ctypes.c_void_p), ("num_materials", ctypes.c_int32),
+                ("emitters", ctypes.c_void_p), ("num_emitters", ctypes.c_int32)]
+
+
+class OrcTraceParams(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("eye", ctypes.c_float * 3), ("ray00", ctypes.c_float * 3), ("ray01", ctypes.c_float * 3),
+                ("ray10", ctypes.c_float * 3), ("ray11", ctypes.c_float * 3),
+                ("time", ctypes.c_float), ("blend_factor", ctypes.c_float),
+                ("max_bounces", ctypes.c_int32), ("num_emitters", ctypes.c_int32),
+                ("max_follows", ctypes.c_int32), ("oob_seeds", ctypes.c_float * 3),
+                ("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32), ("y1", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} missing: run `make oracle`")
+        L = ctypes.CDLL(LIB_PATH)
+        vp = ctypes.c_void_p
+        L.orc_trace.argtypes = [ctypes.POINTER(OrcScene), ctypes.POINTER(OrcTraceParams), vp, vp, vp, vp, vp, vp]
+        L.orc_trace.restype = None
+        L.orc_filter_pass.argtypes = [ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int32, vp, vp, vp,
+                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32]
+        L.orc_filter_pass.restype = None
+        L.orc_filter.argtypes = [ctypes.c_int32, ctypes.c_int32, vp, vp, vp, vp, vp, ctypes.c_int32,
+                                 ctypes.c_float, ctypes.c_float, ctypes.c_float]
+        L.orc_filter.restype = None
+        L.orc_tonemap.argtypes = [ctypes.c_int32, vp, ctypes.c_int32, ctypes.c_float, vp]
+        L.orc_tonemap.restype = None
+        L.orc_set_filter_store_rounding.argtypes = [ctypes.c_int32]
+        L.orc_set_filter_store_rounding.restype = None
+        fp = ctypes.POINTER(ctypes.c_float)
+        L.orc_intersect_box.argtypes = [fp, fp, fp, fp, fp]
+        L.orc_intersect_triangle.argtypes = [fp, fp, fp, fp, fp, fp]
+        L.orc_hash3.argtypes = [ctypes.c_uint32] * 3
+        L.orc_hash3.restype = ctypes.c_uint32
+        L.orc_random3.argtypes = [ctypes.c_float] * 3
+        L.orc_random3.restype = ctypes.c_float
+        L.orc_f32_to_f16_rtz.argtypes = [ctypes.c_float]
+        L.orc_f32_to_f16_rtz.restype = ctypes.c_uint16
+        L.orc_f16_to_f32.argtypes = [ctypes.c_uint16]
+        L.orc_f16_to_f32.restype = ctypes.c_float
+        L.orc_f32_to_snorm8.argtypes = [ctypes.c_float]
+        L.orc_f32_to_snorm8.restype = ctypes.c_int8
+        _lib = L
+    return _lib
+
+
+class Scene:
+    """Keeps the four byte streams alive and exposes them as an orc_scene."""
+
+    def __init__(self, buffers):
+        self._keep = [np.frombuffer(buffers.get(s, b"") or b"\0" * 128, dtype=np.uint8).copy() for s in (3, 4, 5, 6)]
+        sizes = [len(buffers.get(s, b"")) for s in (3, 4, 5, 6)]
+        self.c = OrcScene(self._keep[0].ctypes.data, sizes[0] // 48, self._keep[1].ctypes.data, sizes[1] // 128,
+                          self._keep[2].ctypes.data, sizes[2] // 32, self._keep[3].ctypes.data, sizes[3] // 128)
+
+
+def trace(scene, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.0625, max_bounces=5,
+          num_emitters=None, color=None, rect=None, max_follows=1000, oob='llvmpipe'):
+    """spp dispatches with time_k = time0 + dtime*k, blendFactor_k = k/(k+1) (as tests/golden fixtures)."""
+    L = lib()
+    n = width * height
+    color = np.zeros((height, width, 4), np.float32) if color is None else np.ascontiguousarray(color, np.float32).copy()
+    normal = np.zeros((height, width, 4), np.int8)
+    pos = np.zeros((height, width, 4), np.uint16)
+    tridx = np.full((height, width), -2, np.int32)
+    visits = np.zeros((height, width), np.int32)
+    stats = np.zeros((height, width, 4), np.int32)
+    rays = np.asarray(rays, np.float32).reshape(4, 3)
+    p = OrcTraceParams()
+    p.width, p.height = width, height
+    p.eye[:] = [float(np.float32(v)) for v in eye]
+    p.ray00[:], p.ray01[:], p.ray10[:], p.ray11[:] = rays[0].tolist(), rays[1].tolist(), rays[2].tolist(), rays[3].tolist()
+    p.max_bounces = max_bounces
+    p.num_emitters = scene.c.num_emitters if num_emitters is None else num_emitters
+    p.max_follows = max_follows
+    if rect is not None:
+        p.x0, p.y0, p.x1, p.y1 = rect
+    for k in range(spp):
+        frame = frame0 + k
+        p.time = float(np.float32(time0) + np.float32(dtime) * np.float32(frame))
+        p.blend_factor = float(np.float32(frame) / (np.float32(frame) + np.float32(1.0)))
+        if oob == 'llvmpipe':
+            p.oob_seeds[:] = [float(np.array([max_bounces], np.int32).view(np.float32)[0]), p.blend_factor, p.time]
+        else:
+            p.oob_seeds[:] = [0.0, 0.0, 0.0]
+        L.orc_trace(ctypes.byref(scene.c), ctypes.byref(p), color.ctypes.data, normal.ctypes.data, pos.ctypes.data,
+                    tridx.ctypes.data, visits.ctypes.data, stats.ctypes.data)
+    return dict(color=color, normal=normal, pos=pos.view(np.float16), tridx=tridx, visits=visits, stats=stats)
+
+
+def filter_passes(color, normal, pos, iterations, c_phi0=3.3, n_phi0=1e-2, p_phi0=5.5):
+    """Returns the RGBA16F output of every pass (list of float16 arrays)."""
+    L = lib()
+    h, w = color.shape[:2]
+    color = np.ascontiguousarray(color, np.float32)
+    normal = np.ascontiguousarray(normal, np.int8)
+    pos = np.ascontiguousarray(pos).view(np.uint16)
+    outs = []
+    read, is_f32 = color, 1
+    f = np.float32
+    for i in range(iterations):
+        with np.errstate(divide="ignore"):
+            c_phi = f(1.0) / f(i) * f(c_phi0)
+        p_phi = f(1.0) / f(1 << i) * f(p_phi0)
+        n_phi = f(1.0) / f(1 << i) * f(n_phi0)
+        out = np.zeros((h, w, 4), np.uint16)
+        L.orc_filter_pass(w, h, read.ctypes.data, is_f32, normal.ctypes.data, pos.ctypes.data, out.ctypes.data,
+                          float(c_phi), float(n_phi), float(p_phi), (1 << (i + 1)) - 1)
+        outs.append(out.view(np.float16))
+        read, is_f32 = out, 0
+    return outs

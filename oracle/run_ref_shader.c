@@ -11,7 +11,8 @@
  * The reference outputs neither the primary-hit triangle index nor the node-visit count, so
  * with instrument=1 three integer images are added by text substitution at load time
  * (arithmetic untouched): unit 3 = SI.tridx of bounce 0, unit 4 = `iterations` of the primary
- * intersectGeometry, unit 5 = per-pixel (traversals, node visits, triangle tests, 0) totals.
+ * intersectGeometry, unit 5 = per-pixel (traversals, node visits, triangle tests, bits of rand_seeds[-1 - x%3]) — the
+ * last one records what the reference's out-of-range rand_seeds reads (trace3.cs:284-300) return here.
  *
  * Usage: run_ref_shader job.txt      (key=value lines; floats may be C hex floats)
  *   ref_dir=/root/reference  width= height=  spp=  time0= dtime=  max_bounces=  importance=
@@ -326,7 +327,7 @@ int main(int argc, char **argv) {
                                   " imageStore(o_visits, px, ivec4(g_iter)); }\n");
                 src = replaceOnce(src, "void main(void)", "imageStore(framebuffer, pix, vec4(finalColor, 1.0));",
                                   "imageStore(framebuffer, pix, vec4(finalColor, 1.0));\n"
-                                  "  imageStore(o_stats, pix, ivec4(g_rays, g_visits, g_tests, 0));");
+                                  "  imageStore(o_stats, pix, ivec4(g_rays, g_visits, g_tests, floatBitsToInt(rand_seeds[-1 - (pix.x % 3)])));");
             }
             sh[i] = compile(GL_COMPUTE_SHADER, src, files[i]);
             free(src);
