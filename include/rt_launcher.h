@@ -1,0 +1,189 @@
+/* rt_launcher.h — C-ABI of the MI355X (gfx950) trace + denoise launcher.
+ *
+ * This is the drop-in boundary: it replaces the OpenGL calls that the reference's Tracer,
+ * ComputeShader, BVHContainer, QTable and Filter classes make, one entry point per GL use:
+ *
+ *   rt_upload        ← glBufferData of the std430 byte streams   (reference src/BVH.cpp:378-397,
+ *                                                                   src/QTable.cpp:138-146)
+ *   rt_set_table     ← sample-table / LUT uploads                 (reference src/Tracer.cpp:23-90)
+ *   rt_resize        ← texture allocation RGBA32F / RGBA8_SNORM / RGBA16F
+ *                                                                  (reference src/FrameBuffer.cpp:20-54,
+ *                                                                   src/filter.cpp:47-66)
+ *   rt_trace         ← uniforms + bindings + glDispatchCompute + glMemoryBarrier
+ *                                                                  (reference src/Tracer.cpp:132-198)
+ *   rt_filter        ← Filter::filter's pass loop                 (reference src/filter.cpp:68-104)
+ *   rt_tonemap       ← quad.fs full-screen pass                   (reference src/main.cpp:94-100,
+ *                                                                   src/shaders/quad.fs:10-22)
+ *   rt_readback      ← glGetTexImage                              (reference src/FrameBuffer.cpp:89-99)
+ *
+ * Plain pointers and sizes only.  One rt_ctx per GPU; a context is not thread-safe.  All work is
+ * queued on one HIP stream; rt_sync and rt_readback are the only blocking calls.
+ * Every function returns 0 on success or a negative RT_E* code; rt_last_error gives the text.
+ * Images are stored row 0 = bottom row, like the GL images they replace.
+ *
+ * Library: raytracer_amd/lib/librt_hip.so (hipcc --offload-arch=gfx950).
+ */
+#ifndef RT_LAUNCHER_H
+#define RT_LAUNCHER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum rt_error {
+    RT_OK = 0,
+    RT_EINVAL = -1,   /* bad argument                                  */
+    RT_ENODEV = -2,   /* no usable GPU / HIP error at context creation */
+    RT_ENOMEM = -3,   /* device allocation failed                      */
+    RT_ESTATE = -4,   /* call order: buffers or images missing         */
+    RT_EHIP = -5,     /* a HIP runtime call failed                     */
+    RT_ECORRUPT = -6  /* an uploaded byte stream failed validation     */
+};
+
+/* Buffer slots of rt_upload: the SSBO binding numbers of reference src/Tracer.cpp:173-180. */
+enum rt_slot {
+    RT_SLOT_NODES = 3,
+    RT_SLOT_TRIANGLES = 4,
+    RT_SLOT_MATERIALS = 5,
+    RT_SLOT_EMITTERS = 6,
+    RT_SLOT_VORONOI_NORMALS = 7,
+    RT_SLOT_VORONOI_CENTRES = 8,
+    RT_SLOT_QTABLE = 9,
+    RT_SLOT_QVISITS = 10
+};
+
+/* Tables of rt_set_table (reference src/Tracer.cpp:23-48 LTC LUTs, :50-90 blue-noise tables). */
+enum rt_table {
+    RT_TABLE_SOBOL = 0,    /* 256*256 uint8   (res/sobol_256_256_4spp.data)        */
+    RT_TABLE_SCRAMBLE = 1, /* 128*128*8 uint8 (res/scramble_128_128_8_4spp.data)   */
+    RT_TABLE_RANKING = 2,  /* 128*128*8 uint8 (res/ranking_128_128_8_4spp.data)    */
+    RT_TABLE_LTC1 = 3,     /* 64*64 RGBA32F   (res/ltc1.data)                      */
+    RT_TABLE_LTC2 = 4      /* 64*64 RGBA32F   (res/ltc2.data)                      */
+};
+
+/* Which program rt_trace runs: the shader set a ComputeShader was built from
+ * (reference src/Tracer.cpp:14 builds trace3.cs + geometry + random + qtablehelper). */
+enum rt_kernel {
+    RT_KERNEL_TRACE3 = 0, /* BVH path tracer, trace3.cs::main → trace()                 */
+    RT_KERNEL_TRACE3_RL = 1, /* trace3.cs traceRL(): Q-table guided (dead in the reference's main) */
+    RT_KERNEL_TRACE = 2,  /* box-scene tracer, trace.cs                                  */
+    RT_KERNEL_TRACE1 = 3, /* box scene + rect light, blue-noise sampler + 3-way MIS, trace1.cs */
+    RT_KERNEL_TRACE2 = 4  /* LTC area lights, trace2.cs                                  */
+};
+
+enum rt_flags {
+    RT_FLAG_AUX = 1,       /* also write primary-hit triangle index + node-visit count images */
+    RT_FLAG_PIXEL_STATS = 2, /* also write per-pixel (traversals, node visits, triangle tests, 0)  */
+    RT_FLAG_NO_COUNTERS = 4  /* skip the global ray / visit / test counters                      */
+};
+
+typedef struct rt_rect {
+    int32_t x0, y0, x1, y1; /* [x0,x1) x [y0,y1) in pixels, row 0 = bottom */
+} rt_rect;
+
+/* Per-launch parameters = the uniforms of reference src/Tracer.cpp:140-161 (names kept), plus the
+ * commented-out trace1/trace2 ones (:147-156), plus launcher-specific fields at the end.
+ * `size` must be sizeof(rt_trace_params) (versioning). */
+typedef struct rt_trace_params {
+    uint32_t size;
+    int32_t kernel; /* enum rt_kernel */
+    float eye[3], ray00[3], ray01[3], ray10[3], ray11[3];
+    float time, blendFactor;
+    int32_t importanceSampled, numPoints, numEmitters, maxPhi, maxTheta, maxBounces;
+    int32_t useBlueNoise, multipleImportanceSampled, frameIndex;
+    float phongExponent, specularFactor, roughness;
+    /* launcher-specific */
+    int32_t flags;      /* enum rt_flags */
+    int32_t maxFollows; /* MAX_FOLLOWS of trace3.cs:214; <= 0 means 1000 */
+    /* What rand_seeds[-1], [-2], [-3] read once `seed` wraps (trace3.cs:284-300, undefined
+     * behaviour in the reference).  The host mirror passes what the reference's oracle platform
+     * (Mesa llvmpipe) returns: intBitsToFloat(maxBounces), blendFactor, time.  Zeros = "reads 0". */
+    float oobSeeds[3];
+} rt_trace_params;
+
+typedef struct rt_counters {
+    uint64_t rays;        /* intersectGeometry-equivalent traversals (primary + continuation + shadow) */
+    uint64_t node_visits; /* Σ `iterations` (trace3.cs:227)                                            */
+    uint64_t tri_tests;   /* Σ intersectTriangle calls (trace3.cs:177)                                 */
+    uint64_t shaded_hits; /* closest hits that were shaded                                              */
+    uint64_t paths;       /* pixel-samples                                                              */
+} rt_counters;
+
+/* Accumulated device time, measured with HIP events on the context's stream when profiling is on. */
+typedef struct rt_timings {
+    double trace_ms;  uint64_t trace_launches;
+    double filter_ms; uint64_t filter_launches; /* one launch per à-trous pass */
+    double tonemap_ms; uint64_t tonemap_launches;
+} rt_timings;
+
+enum rt_image {
+    RT_IMAGE_COLOR = 0,    /* RGBA32F accumulation image, 16 B/px (FrameBuffer::texture)       */
+    RT_IMAGE_NORMAL = 1,   /* RGBA8_SNORM, 4 B/px (FrameBuffer::normalTex)                     */
+    RT_IMAGE_POSITION = 2, /* RGBA16F, 8 B/px (FrameBuffer::posTex)                            */
+    RT_IMAGE_FILTERED = 3, /* RGBA16F result of the last rt_filter (Filter::readFrom)           */
+    RT_IMAGE_TRIDX = 4,    /* int32 primary-hit triangle index (RT_FLAG_AUX)                    */
+    RT_IMAGE_VISITS = 5,   /* int32 node-visit count of the primary traversal (RT_FLAG_AUX)     */
+    RT_IMAGE_STATS = 6,    /* 4 x int32 per pixel (RT_FLAG_PIXEL_STATS)                         */
+    RT_IMAGE_LDR = 7       /* RGBA8 result of rt_tonemap                                        */
+};
+
+int rt_create(int device_id, rt_ctx **out);
+void rt_destroy(rt_ctx *ctx);
+const char *rt_last_error(const rt_ctx *ctx);
+
+/* Use an existing HIP stream (hipStream_t passed as void*) instead of the context's own; NULL
+ * switches back.  The caller keeps ownership. */
+int rt_set_stream(rt_ctx *ctx, void *hip_stream);
+
+/* Copy one of the byte streams BVHContainer::bvhToSsbo / QTable::fillQtableSsbo emit.  The host
+ * buffer is borrowed only for the duration of the call.  Nodes and triangles are validated
+ * (links and ranges in bounds) and re-packed privately into aligned device records. */
+int rt_upload(rt_ctx *ctx, int slot, const void *bytes, size_t nbytes);
+int rt_set_table(rt_ctx *ctx, int table, const void *bytes, size_t nbytes);
+
+/* (Re)allocate and clear the images for a width x height frame. */
+int rt_resize(rt_ctx *ctx, int width, int height);
+int rt_clear(rt_ctx *ctx);
+
+/* One dispatch over `tile` (NULL = whole image).  Pixels outside the tile are left untouched. */
+int rt_trace(rt_ctx *ctx, const rt_trace_params *params, const rt_rect *tile);
+
+/* Filter::filter: `iterations` à-trous passes over the colour image using the normal / position
+ * images.  With a tile, every pass covers the tile grown by the step widths of the passes that
+ * follow it, so the tile's final pixels equal those of a whole-image filter as long as the colour
+ * / normal / position images are valid on the tile grown by rt_filter_halo(iterations) pixels
+ * (clipped to the image; beyond the image edge taps read zero, as in the reference). */
+int rt_filter(rt_ctx *ctx, int iterations, float c_phi0, float n_phi0, float p_phi0, const rt_rect *tile);
+int rt_filter_halo(int iterations);
+
+/* quad.fs: 1 - exp(-c * exposure), then pow(1/2.2); source = RT_IMAGE_COLOR or RT_IMAGE_FILTERED. */
+int rt_tonemap(rt_ctx *ctx, int source_image, float exposure, const rt_rect *tile);
+
+/* Blocking copies of an image (whole image, tightly packed rows, row 0 = bottom).
+ * rt_readback → host memory; rt_readback_rect_device → rows of `tile` packed into device memory
+ * the caller owns (e.g. a tensor handed to an RCCL gather); rt_write_rect_device is the inverse. */
+int rt_readback(rt_ctx *ctx, int image, void *dst, size_t nbytes);
+int rt_readback_rect_device(rt_ctx *ctx, int image, const rt_rect *tile, void *dst_device, size_t nbytes);
+int rt_write_rect_device(rt_ctx *ctx, int image, const rt_rect *tile, const void *src_device, size_t nbytes);
+int rt_write_image(rt_ctx *ctx, int image, const void *src_host, size_t nbytes);
+size_t rt_image_pixel_bytes(int image);
+
+int rt_counters_read(rt_ctx *ctx, rt_counters *out); /* blocking */
+int rt_counters_reset(rt_ctx *ctx);
+int rt_profile(rt_ctx *ctx, int enable);             /* HIP-event timing of every launch */
+int rt_timings_read(rt_ctx *ctx, rt_timings *out, int reset); /* blocking */
+int rt_sync(rt_ctx *ctx);
+
+/* Launch geometry of the trace kernel, as ComputeShader::workGroupSize reports it. */
+void rt_work_group_size(int kernel, int out_xyz[3]);
+const char *rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

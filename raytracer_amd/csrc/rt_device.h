@@ -1,0 +1,114 @@
+// rt_device.h — device-side data layout and fp32 helpers shared by the gfx950 kernels.
+//
+// HBM layout (built by rt_upload from the reference's std430 streams, see rt_launcher.hip):
+//   boxes   float4[2*N]   node i → {min.xyz, bits(hitNext)}, {max.xyz, bits(missNext)}   32 B, 32-B aligned
+//   leaves  int2[N]       node i → {firstTri, numTris}                                    8 B
+//   tris48  float4[3*T]   triangle j → {v0,0}, {v1-v0,0}, {v2-v0,0}                      48 B, 16-B aligned
+//   tris128 the reference's 128-B triangle records, untouched (normals, mtlIndex, ...)   shading only
+//   mtls    the reference's 32-B material records; emitters: 128-B records
+// A 32-B box record never straddles a 64-B/128-B line (the reference's 48-B records do); the
+// intersection loops read 48 B per triangle instead of the first 48 B of a 128-B stride.
+//
+// Arithmetic rules (must match the reference shaders as executed by the oracle):
+// every translation unit is compiled with -ffp-contract=off, IEEE divide/sqrt, and vector
+// built-ins are spelt in the measured operation order (dot summed from the last component).
+#ifndef RT_DEVICE_H
+#define RT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rt_launcher.h"
+
+struct RtTri128 { // reference trace3.cs:73-87
+    float v0[3], w0, v1[3], w1, v2[3], w2;
+    float n0[3], p0, n1[3], p1, n2[3];
+    int mtlIndex;
+    float uv0[2], uv1[2], uv2[2];
+    int objId;
+    float pad;
+};
+static_assert(sizeof(RtTri128) == 128, "triangle record");
+
+struct RtMtl { // reference trace3.cs:95-100
+    float Kd[3], Ns, Ke[3];
+    int emitter;
+};
+static_assert(sizeof(RtMtl) == 32, "material record");
+
+struct RtNode48 { // reference trace3.cs:54-65
+    float min[3], pad0, max[3];
+    int hitNext, missNext, firstTri, numTris;
+    float pad1;
+};
+static_assert(sizeof(RtNode48) == 48, "node record");
+
+struct RtScene {
+    const float4 *boxes;
+    const int2 *leaves;
+    const float4 *tris48;
+    const RtTri128 *tris128;
+    const RtMtl *mtls;
+    const RtTri128 *emitters;
+    int numNodes, numTris, numMtls, numEmitters;
+};
+
+struct RtImages {
+    float4 *color;   // RGBA32F
+    uint32_t *normal; // RGBA8_SNORM packed, byte 0 = x
+    uint2 *pos;      // RGBA16F packed
+    int *tridx, *visits;
+    int4 *stats;
+    int width, height;
+};
+
+struct RtCountersDev {
+    unsigned long long rays, node_visits, tri_tests, shaded_hits, paths;
+};
+
+// ---------------------------------------------------------------------------------------
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 F3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+// GLSL dot() as the oracle evaluates it: x*x' + (y*y' + z*z')
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+    return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float rsq(float x) { return 1.0f / sqrtf(x); }
+__device__ __forceinline__ f3 normalize(f3 v) { return v * rsq(dot(v, v)); }
+__device__ __forceinline__ f3 mix(f3 a, f3 b, float t) {
+    return F3(a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z));
+}
+__device__ __forceinline__ f3 reflect(f3 I, f3 N) { return I - N * (2.0f * dot(N, I)); }
+__device__ __forceinline__ f3 rcp3(f3 v) { return F3(1.0f / v.x, 1.0f / v.y, 1.0f / v.z); }
+__device__ __forceinline__ f3 ld3(const float *p) { return F3(p[0], p[1], p[2]); }
+__device__ __forceinline__ f3 xyz(float4 v) { return F3(v.x, v.y, v.z); }
+
+// imageStore to rgba16f truncates (measured on the oracle); v_cvt_pkrtz_f16_f32 does exactly that.
+__device__ __forceinline__ uint32_t pack_half2_rtz(float a, float b) {
+    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
+    h2 h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float half_bits_to_float(uint32_t h16) {
+    return (float)__builtin_bit_cast(_Float16, (unsigned short)h16);
+}
+// imageStore to rgba8_snorm: round-half-even of clamp(x,-1,1)*127; NaN stores 0.
+__device__ __forceinline__ uint32_t snorm8(float x) {
+    float c = fminf(fmaxf(x, -1.0f), 1.0f);
+    if (x != x) c = 0.0f;
+    return (uint32_t)(__float2int_rn(c * 127.0f)) & 0xFFu;
+}
+__device__ __forceinline__ float snorm8_to_float(uint32_t b) {
+    return fmaxf((float)(int)(signed char)(b & 0xFFu) * (1.0f / 127.0f), -1.0f);
+}
+
+#endif

@@ -1,0 +1,605 @@
+// rt_launcher.hip — implementation of the C-ABI in include/rt_launcher.h.
+//
+// Owns all device memory of one GPU context: re-packed scene buffers, the three G-buffer images
+// the reference keeps in GL textures (RGBA32F colour, RGBA8_SNORM normal, RGBA16F position), the
+// two RGBA16F ping-pong images of the filter, auxiliary ID / statistics images and counters.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+
+hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace_params &p, const rt_rect &tile,
+                          RtCountersDev *counters, hipStream_t stream);
+hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const uint32_t *normal, const uint2 *pos,
+                          uint2 *out, int W, int H, const rt_rect &rect, float c_phi, float n_phi, float p_phi,
+                          int step, hipStream_t stream);
+hipError_t rtLaunchTonemap(const float4 *colorF32, const uint2 *colorF16, uint32_t *out, int W, const rt_rect &rect,
+                           float exposure, hipStream_t stream);
+int rtAtrousMaxStep();
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+enum TimeKind { TK_TRACE = 0, TK_FILTER = 1, TK_TONEMAP = 2 };
+
+struct TimedSpan {
+    hipEvent_t start, stop;
+    int kind;
+};
+
+} // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    // scene
+    DevBuf boxes, leaves, tris48, tris128, mtls, emitters, raw[11], tables[5];
+    int numNodes = 0, numTris = 0, numMtls = 0, numEmitters = 0;
+    int maxTriEnd = 0; // largest firstTri+numTris over the nodes, checked against numTris at launch
+
+    // images
+    int width = 0, height = 0;
+    DevBuf color, normal, pos, filt[2], tridx, visits, stats, ldr;
+    int filteredIndex = -1; // which of filt[] holds the result of the last rt_filter
+
+    DevBuf counters;
+    bool profile = false;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> eventPool;
+    double accMs[3] = {0, 0, 0};
+    uint64_t accN[3] = {0, 0, 0};
+};
+
+namespace {
+
+int fail(rt_ctx *c, int code, const std::string &msg) {
+    if (c) c->error = msg;
+    return code;
+}
+
+int hipFail(rt_ctx *c, hipError_t e, const char *what) {
+    return fail(c, e == hipErrorOutOfMemory ? RT_ENOMEM : RT_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, call)                                      \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return hipFail(ctx, e_, #call);   \
+    } while (0)
+
+int bind(rt_ctx *c) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    return RT_OK;
+}
+
+int ensure(rt_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.p && b.bytes >= bytes) return RT_OK;
+    if (b.p) {
+        HIP_TRY(c, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return RT_OK;
+}
+
+int uploadTo(rt_ctx *c, DevBuf &b, const void *src, size_t bytes) {
+    int r = ensure(c, b, bytes);
+    if (r) return r;
+    if (bytes) {
+        // the caller's buffer is only borrowed for this call: synchronous copy
+        HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return RT_OK;
+}
+
+void releaseBuf(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+hipEvent_t takeEvent(rt_ctx *c) {
+    if (!c->eventPool.empty()) {
+        hipEvent_t e = c->eventPool.back();
+        c->eventPool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+// Fold finished spans into the accumulators (blocks until the last recorded one has finished).
+int drainSpans(rt_ctx *c) {
+    for (TimedSpan &s : c->spans) {
+        HIP_TRY(c, hipEventSynchronize(s.stop));
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, s.start, s.stop));
+        c->accMs[s.kind] += ms;
+        c->accN[s.kind] += 1;
+        c->eventPool.push_back(s.start);
+        c->eventPool.push_back(s.stop);
+    }
+    c->spans.clear();
+    return RT_OK;
+}
+
+struct SpanGuard { // records start on construction, stop on end()
+    rt_ctx *c;
+    TimedSpan s;
+    bool on;
+    SpanGuard(rt_ctx *c, int kind) : c(c), on(c->profile) {
+        if (on) {
+            s.kind = kind;
+            s.start = takeEvent(c);
+            s.stop = takeEvent(c);
+            (void)hipEventRecord(s.start, c->stream);
+        }
+    }
+    void end() {
+        if (on) {
+            (void)hipEventRecord(s.stop, c->stream);
+            c->spans.push_back(s);
+            on = false;
+        }
+    }
+};
+
+bool rectOk(const rt_ctx *c, const rt_rect &r) {
+    return r.x0 >= 0 && r.y0 >= 0 && r.x1 <= c->width && r.y1 <= c->height && r.x0 <= r.x1 && r.y0 <= r.y1;
+}
+
+rt_rect fullRect(const rt_ctx *c) { return rt_rect{0, 0, c->width, c->height}; }
+
+struct ImageRef {
+    void *p;
+    size_t pixelBytes;
+};
+
+ImageRef imageOf(rt_ctx *c, int image) {
+    switch (image) {
+    case RT_IMAGE_COLOR: return {c->color.p, 16};
+    case RT_IMAGE_NORMAL: return {c->normal.p, 4};
+    case RT_IMAGE_POSITION: return {c->pos.p, 8};
+    case RT_IMAGE_FILTERED: return {c->filteredIndex >= 0 ? c->filt[c->filteredIndex].p : nullptr, 8};
+    case RT_IMAGE_TRIDX: return {c->tridx.p, 4};
+    case RT_IMAGE_VISITS: return {c->visits.p, 4};
+    case RT_IMAGE_STATS: return {c->stats.p, 16};
+    case RT_IMAGE_LDR: return {c->ldr.p, 4};
+    default: return {nullptr, 0};
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+const char *rt_version(void) { return "raytracer_amd gfx950 launcher 0.1 (round 1)"; }
+
+void rt_work_group_size(int kernel, int out_xyz[3]) {
+    (void)kernel;
+    if (!out_xyz) return;
+    out_xyz[0] = 16; // a 256-thread block covers a 16x16 pixel tile (four 8x8 waves)
+    out_xyz[1] = 16;
+    out_xyz[2] = 1;
+}
+
+size_t rt_image_pixel_bytes(int image) {
+    switch (image) {
+    case RT_IMAGE_COLOR: case RT_IMAGE_STATS: return 16;
+    case RT_IMAGE_POSITION: case RT_IMAGE_FILTERED: return 8;
+    case RT_IMAGE_NORMAL: case RT_IMAGE_TRIDX: case RT_IMAGE_VISITS: case RT_IMAGE_LDR: return 4;
+    default: return 0;
+    }
+}
+
+int rt_create(int device_id, rt_ctx **out) {
+    if (!out) return RT_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RT_ENODEV;
+    if (device_id < 0 || device_id >= n) return RT_ENODEV;
+    rt_ctx *c = new rt_ctx;
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return RT_ENODEV;
+    }
+    c->stream = c->ownStream;
+    if (ensure(c, c->counters, sizeof(RtCountersDev)) != RT_OK ||
+        hipMemsetAsync(c->counters.p, 0, sizeof(RtCountersDev), c->stream) != hipSuccess) {
+        (void)hipStreamDestroy(c->ownStream);
+        delete c;
+        return RT_ENOMEM;
+    }
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (TimedSpan &s : c->spans) {
+        (void)hipEventDestroy(s.start);
+        (void)hipEventDestroy(s.stop);
+    }
+    for (hipEvent_t e : c->eventPool) (void)hipEventDestroy(e);
+    DevBuf *all[] = {&c->boxes, &c->leaves, &c->tris48, &c->tris128, &c->mtls, &c->emitters, &c->color, &c->normal,
+                     &c->pos, &c->filt[0], &c->filt[1], &c->tridx, &c->visits, &c->stats, &c->ldr, &c->counters};
+    for (DevBuf *b : all) releaseBuf(*b);
+    for (DevBuf &b : c->raw) releaseBuf(b);
+    for (DevBuf &b : c->tables) releaseBuf(b);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+const char *rt_last_error(const rt_ctx *c) { return c ? c->error.c_str() : "null context"; }
+
+int rt_set_stream(rt_ctx *c, void *hip_stream) {
+    if (!c) return RT_EINVAL;
+    int r = bind(c);
+    if (r) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
+    return RT_OK;
+}
+
+int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
+    if (!c) return RT_EINVAL;
+    if (!bytes && nbytes) return fail(c, RT_EINVAL, "rt_upload: null bytes");
+    int r = bind(c);
+    if (r) return r;
+    switch (slot) {
+    case RT_SLOT_NODES: {
+        if (nbytes % sizeof(RtNode48)) return fail(c, RT_EINVAL, "rt_upload: node stream is not a multiple of 48 bytes");
+        const size_t n = nbytes / sizeof(RtNode48);
+        if (n == 0 || n > 0x7FFFFFFFu / 2) return fail(c, RT_EINVAL, "rt_upload: node count out of range");
+        const RtNode48 *src = static_cast<const RtNode48 *>(bytes);
+        std::vector<float4> boxes(2 * n);
+        std::vector<int2> leaves(n);
+        long long maxEnd = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const RtNode48 &s = src[i];
+            if (s.hitNext < -1 || s.hitNext >= (long long)n || s.missNext < -1 || s.missNext >= (long long)n)
+                return fail(c, RT_ECORRUPT, "rt_upload: node link out of range at node " + std::to_string(i));
+            if (s.numTris < 0 || s.firstTri < 0)
+                return fail(c, RT_ECORRUPT, "rt_upload: negative triangle range at node " + std::to_string(i));
+            if (s.numTris > 0 && (long long)s.firstTri + s.numTris > maxEnd) maxEnd = (long long)s.firstTri + s.numTris;
+            float hb, mb;
+            std::memcpy(&hb, &s.hitNext, 4);
+            std::memcpy(&mb, &s.missNext, 4);
+            boxes[2 * i] = make_float4(s.min[0], s.min[1], s.min[2], hb);
+            boxes[2 * i + 1] = make_float4(s.max[0], s.max[1], s.max[2], mb);
+            leaves[i] = make_int2(s.firstTri, s.numTris);
+        }
+        if (maxEnd > 0x7FFFFFFF) return fail(c, RT_ECORRUPT, "rt_upload: triangle range overflow");
+        if ((r = uploadTo(c, c->boxes, boxes.data(), boxes.size() * sizeof(float4)))) return r;
+        if ((r = uploadTo(c, c->leaves, leaves.data(), leaves.size() * sizeof(int2)))) return r;
+        c->numNodes = (int)n;
+        c->maxTriEnd = (int)maxEnd;
+        return RT_OK;
+    }
+    case RT_SLOT_TRIANGLES: {
+        if (nbytes % sizeof(RtTri128)) return fail(c, RT_EINVAL, "rt_upload: triangle stream is not a multiple of 128 bytes");
+        const size_t n = nbytes / sizeof(RtTri128);
+        if (n > 0x7FFFFFFFu / 3) return fail(c, RT_EINVAL, "rt_upload: triangle count out of range");
+        const RtTri128 *src = static_cast<const RtTri128 *>(bytes);
+        std::vector<float4> t48(3 * n);
+        for (size_t i = 0; i < n; ++i) {
+            const RtTri128 &s = src[i];
+            // e1 = v1 - v0, e2 = v2 - v0: the first two operations of geometry.glsl:32, done once
+            t48[3 * i] = make_float4(s.v0[0], s.v0[1], s.v0[2], 0.0f);
+            t48[3 * i + 1] = make_float4(s.v1[0] - s.v0[0], s.v1[1] - s.v0[1], s.v1[2] - s.v0[2], 0.0f);
+            t48[3 * i + 2] = make_float4(s.v2[0] - s.v0[0], s.v2[1] - s.v0[1], s.v2[2] - s.v0[2], 0.0f);
+        }
+        if ((r = uploadTo(c, c->tris48, t48.data(), t48.size() * sizeof(float4)))) return r;
+        if ((r = uploadTo(c, c->tris128, bytes, nbytes))) return r;
+        c->numTris = (int)n;
+        return RT_OK;
+    }
+    case RT_SLOT_MATERIALS:
+        if (nbytes % sizeof(RtMtl)) return fail(c, RT_EINVAL, "rt_upload: material stream is not a multiple of 32 bytes");
+        if ((r = uploadTo(c, c->mtls, bytes, nbytes))) return r;
+        c->numMtls = (int)(nbytes / sizeof(RtMtl));
+        return RT_OK;
+    case RT_SLOT_EMITTERS:
+        if (nbytes % sizeof(RtTri128)) return fail(c, RT_EINVAL, "rt_upload: emitter stream is not a multiple of 128 bytes");
+        if ((r = uploadTo(c, c->emitters, bytes, nbytes))) return r;
+        c->numEmitters = (int)(nbytes / sizeof(RtTri128));
+        return RT_OK;
+    case RT_SLOT_VORONOI_NORMALS: case RT_SLOT_VORONOI_CENTRES: case RT_SLOT_QTABLE: case RT_SLOT_QVISITS:
+        return uploadTo(c, c->raw[slot], bytes, nbytes);
+    default:
+        return fail(c, RT_EINVAL, "rt_upload: unknown slot " + std::to_string(slot));
+    }
+}
+
+int rt_set_table(rt_ctx *c, int table, const void *bytes, size_t nbytes) {
+    if (!c) return RT_EINVAL;
+    if (table < 0 || table > RT_TABLE_LTC2 || !bytes) return fail(c, RT_EINVAL, "rt_set_table: bad argument");
+    static const size_t expect[5] = {65536, 131072, 131072, 65536, 65536};
+    if (nbytes != expect[table]) return fail(c, RT_EINVAL, "rt_set_table: unexpected table size");
+    int r = bind(c);
+    if (r) return r;
+    return uploadTo(c, c->tables[table], bytes, nbytes);
+}
+
+int rt_clear(rt_ctx *c) {
+    if (!c) return RT_EINVAL;
+    if (!c->color.p) return fail(c, RT_ESTATE, "rt_clear: no images (call rt_resize)");
+    int r = bind(c);
+    if (r) return r;
+    const size_t n = (size_t)c->width * c->height;
+    HIP_TRY(c, hipMemsetAsync(c->color.p, 0, n * 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->normal.p, 0, n * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->pos.p, 0, n * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->filt[0].p, 0, n * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->filt[1].p, 0, n * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->tridx.p, 0xFF, n * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->visits.p, 0, n * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, n * 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->ldr.p, 0, n * 4, c->stream));
+    c->filteredIndex = -1;
+    return RT_OK;
+}
+
+int rt_resize(rt_ctx *c, int width, int height) {
+    if (!c) return RT_EINVAL;
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 28))
+        return fail(c, RT_EINVAL, "rt_resize: bad size");
+    int r = bind(c);
+    if (r) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)width * height;
+    if ((r = ensure(c, c->color, n * 16)) || (r = ensure(c, c->normal, n * 4)) || (r = ensure(c, c->pos, n * 8)) ||
+        (r = ensure(c, c->filt[0], n * 8)) || (r = ensure(c, c->filt[1], n * 8)) || (r = ensure(c, c->tridx, n * 4)) ||
+        (r = ensure(c, c->visits, n * 4)) || (r = ensure(c, c->stats, n * 16)) || (r = ensure(c, c->ldr, n * 4)))
+        return r;
+    c->width = width;
+    c->height = height;
+    return rt_clear(c);
+}
+
+int rt_trace(rt_ctx *c, const rt_trace_params *p, const rt_rect *tile) {
+    if (!c || !p) return RT_EINVAL;
+    if (p->size != sizeof(rt_trace_params)) return fail(c, RT_EINVAL, "rt_trace: params.size mismatch");
+    if (!c->color.p) return fail(c, RT_ESTATE, "rt_trace: no images (call rt_resize)");
+    const rt_rect r = tile ? *tile : fullRect(c);
+    if (!rectOk(c, r)) return fail(c, RT_EINVAL, "rt_trace: tile outside the image");
+    if (p->maxBounces < 0 || p->maxBounces > 1024) return fail(c, RT_EINVAL, "rt_trace: maxBounces out of range");
+    int rc = bind(c);
+    if (rc) return rc;
+    switch (p->kernel) {
+    case RT_KERNEL_TRACE3: {
+        if (!c->boxes.p || !c->tris48.p || !c->mtls.p)
+            return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
+        if (c->maxTriEnd > c->numTris)
+            return fail(c, RT_ECORRUPT, "rt_trace: a leaf references triangles beyond the uploaded triangle stream");
+        RtScene sc;
+        sc.boxes = (const float4 *)c->boxes.p;
+        sc.leaves = (const int2 *)c->leaves.p;
+        sc.tris48 = (const float4 *)c->tris48.p;
+        sc.tris128 = (const RtTri128 *)c->tris128.p;
+        sc.mtls = (const RtMtl *)c->mtls.p;
+        sc.emitters = (const RtTri128 *)c->emitters.p;
+        sc.numNodes = c->numNodes;
+        sc.numTris = c->numTris;
+        sc.numMtls = c->numMtls;
+        sc.numEmitters = c->emitters.p ? c->numEmitters : 0;
+        RtImages img;
+        img.color = (float4 *)c->color.p;
+        img.normal = (uint32_t *)c->normal.p;
+        img.pos = (uint2 *)c->pos.p;
+        img.tridx = (int *)c->tridx.p;
+        img.visits = (int *)c->visits.p;
+        img.stats = (int4 *)c->stats.p;
+        img.width = c->width;
+        img.height = c->height;
+        SpanGuard span(c, TK_TRACE);
+        hipError_t e = rtLaunchTrace3(sc, img, *p, r, (RtCountersDev *)c->counters.p, c->stream);
+        span.end();
+        if (e != hipSuccess) return hipFail(c, e, "trace3 launch");
+        return RT_OK;
+    }
+    default:
+        return fail(c, RT_EINVAL, "rt_trace: kernel " + std::to_string(p->kernel) + " is not available in this build");
+    }
+}
+
+int rt_filter_halo(int iterations) {
+    int h = 0;
+    for (int i = 0; i < iterations; ++i) h += (1 << (i + 1)) - 1;
+    return h;
+}
+
+int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi0, const rt_rect *tile) {
+    if (!c) return RT_EINVAL;
+    if (!c->color.p) return fail(c, RT_ESTATE, "rt_filter: no images (call rt_resize)");
+    if (iterations < 0 || iterations > 30) return fail(c, RT_EINVAL, "rt_filter: iterations out of range");
+    const rt_rect target = tile ? *tile : fullRect(c);
+    if (!rectOk(c, target)) return fail(c, RT_EINVAL, "rt_filter: tile outside the image");
+    if (iterations > 0 && (1 << iterations) - 1 > rtAtrousMaxStep())
+        return fail(c, RT_EINVAL, "rt_filter: step width beyond the LDS tile limit (iterations <= 6)");
+    int rc = bind(c);
+    if (rc) return rc;
+    // Filter::filter, reference src/filter.cpp:68-104
+    const float4 *readF32 = (const float4 *)c->color.p;
+    const uint2 *readF16 = nullptr;
+    int write = 0;
+    for (int i = 0; i < iterations; ++i) {
+        const float c_phi = 1.0f / (float)i * c_phi0; // +inf at i = 0, as the reference computes it
+        const float p_phi = 1.0f / (float)(1 << i) * p_phi0;
+        const float n_phi = 1.0f / (float)(1 << i) * n_phi0;
+        const int step = (1 << (i + 1)) - 1;
+        // the passes after this one reach (sum of their steps) pixels beyond the target tile
+        int grow = 0;
+        for (int j = i + 1; j < iterations; ++j) grow += (1 << (j + 1)) - 1;
+        rt_rect r;
+        r.x0 = target.x0 - grow < 0 ? 0 : target.x0 - grow;
+        r.y0 = target.y0 - grow < 0 ? 0 : target.y0 - grow;
+        r.x1 = target.x1 + grow > c->width ? c->width : target.x1 + grow;
+        r.y1 = target.y1 + grow > c->height ? c->height : target.y1 + grow;
+        SpanGuard span(c, TK_FILTER);
+        hipError_t e = rtLaunchAtrous(readF32, readF16, (const uint32_t *)c->normal.p, (const uint2 *)c->pos.p,
+                                      (uint2 *)c->filt[write].p, c->width, c->height, r, c_phi, n_phi, p_phi, step,
+                                      c->stream);
+        span.end();
+        if (e != hipSuccess) return hipFail(c, e, "atrous launch");
+        readF32 = nullptr;
+        readF16 = (const uint2 *)c->filt[write].p;
+        c->filteredIndex = write;
+        write ^= 1;
+    }
+    return RT_OK;
+}
+
+int rt_tonemap(rt_ctx *c, int source_image, float exposure, const rt_rect *tile) {
+    if (!c) return RT_EINVAL;
+    if (!c->color.p) return fail(c, RT_ESTATE, "rt_tonemap: no images (call rt_resize)");
+    const rt_rect r = tile ? *tile : fullRect(c);
+    if (!rectOk(c, r)) return fail(c, RT_EINVAL, "rt_tonemap: tile outside the image");
+    const float4 *f32 = nullptr;
+    const uint2 *f16 = nullptr;
+    if (source_image == RT_IMAGE_COLOR) f32 = (const float4 *)c->color.p;
+    else if (source_image == RT_IMAGE_FILTERED) {
+        if (c->filteredIndex < 0) return fail(c, RT_ESTATE, "rt_tonemap: no filtered image yet");
+        f16 = (const uint2 *)c->filt[c->filteredIndex].p;
+    } else return fail(c, RT_EINVAL, "rt_tonemap: source must be RT_IMAGE_COLOR or RT_IMAGE_FILTERED");
+    int rc = bind(c);
+    if (rc) return rc;
+    SpanGuard span(c, TK_TONEMAP);
+    hipError_t e = rtLaunchTonemap(f32, f16, (uint32_t *)c->ldr.p, c->width, r, exposure, c->stream);
+    span.end();
+    if (e != hipSuccess) return hipFail(c, e, "tonemap launch");
+    return RT_OK;
+}
+
+int rt_readback(rt_ctx *c, int image, void *dst, size_t nbytes) {
+    if (!c || !dst) return RT_EINVAL;
+    const ImageRef im = imageOf(c, image);
+    if (!im.p) return fail(c, RT_ESTATE, "rt_readback: image not available");
+    const size_t need = (size_t)c->width * c->height * im.pixelBytes;
+    if (nbytes != need) return fail(c, RT_EINVAL, "rt_readback: size mismatch, need " + std::to_string(need));
+    int rc = bind(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(dst, im.p, need, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_write_image(rt_ctx *c, int image, const void *src, size_t nbytes) {
+    if (!c || !src) return RT_EINVAL;
+    if (image == RT_IMAGE_FILTERED && c->filteredIndex < 0 && c->filt[0].p) c->filteredIndex = 0;
+    const ImageRef im = imageOf(c, image);
+    if (!im.p) return fail(c, RT_ESTATE, "rt_write_image: image not available");
+    const size_t need = (size_t)c->width * c->height * im.pixelBytes;
+    if (nbytes != need) return fail(c, RT_EINVAL, "rt_write_image: size mismatch, need " + std::to_string(need));
+    int rc = bind(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(im.p, src, need, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+static int rectCopy(rt_ctx *c, int image, const rt_rect *tile, void *dev, size_t nbytes, bool toCaller) {
+    if (!c || !dev) return RT_EINVAL;
+    if (image == RT_IMAGE_FILTERED && !toCaller && c->filteredIndex < 0 && c->filt[0].p) c->filteredIndex = 0;
+    const ImageRef im = imageOf(c, image);
+    if (!im.p) return fail(c, RT_ESTATE, "rect copy: image not available");
+    const rt_rect r = tile ? *tile : fullRect(c);
+    if (!rectOk(c, r)) return fail(c, RT_EINVAL, "rect copy: tile outside the image");
+    const size_t rowBytes = (size_t)(r.x1 - r.x0) * im.pixelBytes, rows = (size_t)(r.y1 - r.y0);
+    if (nbytes != rowBytes * rows) return fail(c, RT_EINVAL, "rect copy: size mismatch");
+    if (rowBytes == 0 || rows == 0) return RT_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    char *imgAt = (char *)im.p + ((size_t)r.y0 * c->width + r.x0) * im.pixelBytes;
+    const size_t pitch = (size_t)c->width * im.pixelBytes;
+    if (toCaller) HIP_TRY(c, hipMemcpy2DAsync(dev, rowBytes, imgAt, pitch, rowBytes, rows, hipMemcpyDeviceToDevice, c->stream));
+    else HIP_TRY(c, hipMemcpy2DAsync(imgAt, pitch, dev, rowBytes, rowBytes, rows, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_readback_rect_device(rt_ctx *c, int image, const rt_rect *tile, void *dst_device, size_t nbytes) {
+    return rectCopy(c, image, tile, dst_device, nbytes, true);
+}
+
+int rt_write_rect_device(rt_ctx *c, int image, const rt_rect *tile, const void *src_device, size_t nbytes) {
+    return rectCopy(c, image, tile, const_cast<void *>(src_device), nbytes, false);
+}
+
+int rt_counters_read(rt_ctx *c, rt_counters *out) {
+    if (!c || !out) return RT_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    RtCountersDev h;
+    HIP_TRY(c, hipMemcpyAsync(&h, c->counters.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    out->rays = h.rays;
+    out->node_visits = h.node_visits;
+    out->tri_tests = h.tri_tests;
+    out->shaded_hits = h.shaded_hits;
+    out->paths = h.paths;
+    return RT_OK;
+}
+
+int rt_counters_reset(rt_ctx *c) {
+    if (!c) return RT_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(RtCountersDev), c->stream));
+    return RT_OK;
+}
+
+int rt_profile(rt_ctx *c, int enable) {
+    if (!c) return RT_EINVAL;
+    c->profile = enable != 0;
+    return RT_OK;
+}
+
+int rt_timings_read(rt_ctx *c, rt_timings *out, int reset) {
+    if (!c || !out) return RT_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    if ((rc = drainSpans(c))) return rc;
+    out->trace_ms = c->accMs[TK_TRACE];
+    out->trace_launches = c->accN[TK_TRACE];
+    out->filter_ms = c->accMs[TK_FILTER];
+    out->filter_launches = c->accN[TK_FILTER];
+    out->tonemap_ms = c->accMs[TK_TONEMAP];
+    out->tonemap_launches = c->accN[TK_TONEMAP];
+    if (reset)
+        for (int k = 0; k < 3; ++k) {
+            c->accMs[k] = 0;
+            c->accN[k] = 0;
+        }
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx *c) {
+    if (!c) return RT_EINVAL;
+    int rc = bind(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,244 @@
+"""ctypes binding of librt_hip.so (include/rt_launcher.h): the gfx950 trace + denoise launcher.
+
+There is no CPU fallback: if the library is missing or no GPU is usable, this raises."""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librt_hip.so")
+
+(IMAGE_COLOR, IMAGE_NORMAL, IMAGE_POSITION, IMAGE_FILTERED, IMAGE_TRIDX, IMAGE_VISITS, IMAGE_STATS,
+ IMAGE_LDR) = range(8)
+KERNEL_TRACE3, KERNEL_TRACE3_RL, KERNEL_TRACE, KERNEL_TRACE1, KERNEL_TRACE2 = range(5)
+FLAG_AUX, FLAG_PIXEL_STATS, FLAG_NO_COUNTERS = 1, 2, 4
+TABLE_SOBOL, TABLE_SCRAMBLE, TABLE_RANKING, TABLE_LTC1, TABLE_LTC2 = range(5)
+
+_IMAGE_DTYPES = {IMAGE_COLOR: (np.float32, 4), IMAGE_NORMAL: (np.int8, 4), IMAGE_POSITION: (np.float16, 4),
+                 IMAGE_FILTERED: (np.float16, 4), IMAGE_TRIDX: (np.int32, 1), IMAGE_VISITS: (np.int32, 1),
+                 IMAGE_STATS: (np.int32, 4), IMAGE_LDR: (np.uint8, 4)}
+
+
+class Rect(ctypes.Structure):
+    _fields_ = [("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32), ("y1", ctypes.c_int32)]
+
+
+class TraceParams(ctypes.Structure):
+    _fields_ = [("size", ctypes.c_uint32), ("kernel", ctypes.c_int32),
+                ("eye", ctypes.c_float * 3), ("ray00", ctypes.c_float * 3), ("ray01", ctypes.c_float * 3),
+                ("ray10", ctypes.c_float * 3), ("ray11", ctypes.c_float * 3),
+                ("time", ctypes.c_float), ("blendFactor", ctypes.c_float),
+                ("importanceSampled", ctypes.c_int32), ("numPoints", ctypes.c_int32),
+                ("numEmitters", ctypes.c_int32), ("maxPhi", ctypes.c_int32), ("maxTheta", ctypes.c_int32),
+                ("maxBounces", ctypes.c_int32),
+                ("useBlueNoise", ctypes.c_int32), ("multipleImportanceSampled", ctypes.c_int32),
+                ("frameIndex", ctypes.c_int32),
+                ("phongExponent", ctypes.c_float), ("specularFactor", ctypes.c_float), ("roughness", ctypes.c_float),
+                ("flags", ctypes.c_int32), ("maxFollows", ctypes.c_int32), ("oobSeeds", ctypes.c_float * 3)]
+
+
+class Counters(ctypes.Structure):
+    _fields_ = [("rays", ctypes.c_uint64), ("node_visits", ctypes.c_uint64), ("tri_tests", ctypes.c_uint64),
+                ("shaded_hits", ctypes.c_uint64), ("paths", ctypes.c_uint64)]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [("trace_ms", ctypes.c_double), ("trace_launches", ctypes.c_uint64),
+                ("filter_ms", ctypes.c_double), ("filter_launches", ctypes.c_uint64),
+                ("tonemap_ms", ctypes.c_double), ("tonemap_launches", ctypes.c_uint64)]
+
+
+EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_upload", "rt_set_table", "rt_resize",
+           "rt_clear", "rt_trace", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
+           "rt_readback_rect_device", "rt_write_rect_device", "rt_write_image", "rt_image_pixel_bytes",
+           "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
+           "rt_work_group_size", "rt_version"]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: the HIP extension must be built (make hip); "
+                               "there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i32, sz, fl = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_float
+        rp = ctypes.POINTER(Rect)
+        L.rt_create.argtypes = [i32, ctypes.POINTER(vp)]
+        L.rt_destroy.argtypes = [vp]
+        L.rt_destroy.restype = None
+        L.rt_last_error.argtypes = [vp]
+        L.rt_last_error.restype = ctypes.c_char_p
+        L.rt_set_stream.argtypes = [vp, vp]
+        L.rt_upload.argtypes = [vp, i32, vp, sz]
+        L.rt_set_table.argtypes = [vp, i32, vp, sz]
+        L.rt_resize.argtypes = [vp, i32, i32]
+        L.rt_clear.argtypes = [vp]
+        L.rt_trace.argtypes = [vp, ctypes.POINTER(TraceParams), rp]
+        L.rt_filter.argtypes = [vp, i32, fl, fl, fl, rp]
+        L.rt_filter_halo.argtypes = [i32]
+        L.rt_tonemap.argtypes = [vp, i32, fl, rp]
+        L.rt_readback.argtypes = [vp, i32, vp, sz]
+        L.rt_readback_rect_device.argtypes = [vp, i32, rp, vp, sz]
+        L.rt_write_rect_device.argtypes = [vp, i32, rp, vp, sz]
+        L.rt_write_image.argtypes = [vp, i32, vp, sz]
+        L.rt_image_pixel_bytes.argtypes = [i32]
+        L.rt_image_pixel_bytes.restype = sz
+        L.rt_counters_read.argtypes = [vp, ctypes.POINTER(Counters)]
+        L.rt_counters_reset.argtypes = [vp]
+        L.rt_profile.argtypes = [vp, i32]
+        L.rt_timings_read.argtypes = [vp, ctypes.POINTER(Timings), i32]
+        L.rt_sync.argtypes = [vp]
+        L.rt_work_group_size.argtypes = [i32, ctypes.POINTER(ctypes.c_int * 3)]
+        L.rt_work_group_size.restype = None
+        L.rt_version.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def make_params(rays, eye, time, blend_factor, max_bounces, num_emitters, flags=0, kernel=KERNEL_TRACE3,
+                max_follows=1000, oob="llvmpipe"):
+    """Fill rt_trace_params the way Tracer::trace does (reference src/Tracer.cpp:139-161)."""
+    p = TraceParams()
+    p.size = ctypes.sizeof(TraceParams)
+    p.kernel = kernel
+    rays = np.asarray(rays, np.float32).reshape(4, 3)
+    p.eye[:] = [float(np.float32(v)) for v in eye]
+    p.ray00[:], p.ray01[:], p.ray10[:], p.ray11[:] = (rays[0].tolist(), rays[1].tolist(), rays[2].tolist(),
+                                                      rays[3].tolist())
+    p.time = float(time)
+    p.blendFactor = float(blend_factor)
+    p.importanceSampled = 1
+    p.numPoints, p.maxPhi, p.maxTheta = 100, 10, 10
+    p.numEmitters = num_emitters
+    p.maxBounces = max_bounces
+    p.flags = flags
+    p.maxFollows = max_follows
+    if oob == "llvmpipe":
+        p.oobSeeds[:] = [float(np.array([max_bounces], np.int32).view(np.float32)[0]), p.blendFactor, p.time]
+    else:
+        p.oobSeeds[:] = [0.0, 0.0, 0.0]
+    return p
+
+
+class Context:
+    """One rt_ctx (one GPU)."""
+
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        r = lib().rt_create(device, ctypes.byref(h))
+        if r != 0:
+            raise RtError(f"rt_create(device={device}) failed with {r}: no usable GPU (there is no CPU fallback)")
+        self._h = h
+        self.width = self.height = 0
+        self.num_emitters = 0
+
+    def _check(self, r, what):
+        if r != 0:
+            raise RtError(f"{what}: {r}: {lib().rt_last_error(self._h).decode()}")
+
+    def upload(self, slot, data):
+        data = bytes(data)
+        buf = (ctypes.c_char * max(len(data), 1)).from_buffer_copy(data or b"\0")
+        self._check(lib().rt_upload(self._h, slot, buf, len(data)), f"rt_upload({slot})")
+        if slot == 6:
+            self.num_emitters = len(data) // 128
+
+    def upload_scene(self, buffers):
+        for slot in sorted(buffers):
+            if buffers[slot] or slot <= 6:
+                self.upload(slot, buffers[slot])
+
+    def set_table(self, table, data):
+        data = bytes(data)
+        self._check(lib().rt_set_table(self._h, table, data, len(data)), f"rt_set_table({table})")
+
+    def resize(self, width, height):
+        self._check(lib().rt_resize(self._h, width, height), "rt_resize")
+        self.width, self.height = width, height
+
+    def clear(self):
+        self._check(lib().rt_clear(self._h), "rt_clear")
+
+    def set_stream(self, stream_handle):
+        self._check(lib().rt_set_stream(self._h, ctypes.c_void_p(stream_handle)), "rt_set_stream")
+
+    @staticmethod
+    def _rect(rect):
+        return None if rect is None else ctypes.byref(Rect(*rect))
+
+    def trace(self, params, rect=None):
+        self._check(lib().rt_trace(self._h, ctypes.byref(params), self._rect(rect)), "rt_trace")
+
+    def trace_samples(self, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.0625, max_bounces=5, flags=0,
+                      rect=None, num_emitters=None, oob="llvmpipe", max_follows=1000):
+        """spp dispatches with time_k = time0 + dtime*k and blendFactor_k = k/(k+1)."""
+        ne = self.num_emitters if num_emitters is None else num_emitters
+        for k in range(spp):
+            frame = frame0 + k
+            t = np.float32(time0) + np.float32(dtime) * np.float32(frame)
+            bf = np.float32(frame) / (np.float32(frame) + np.float32(1.0))
+            self.trace(make_params(rays, eye, t, bf, max_bounces, ne, flags, max_follows=max_follows, oob=oob), rect)
+
+    def filter(self, iterations, c_phi0=3.3, n_phi0=1e-2, p_phi0=5.5, rect=None):
+        self._check(lib().rt_filter(self._h, iterations, c_phi0, n_phi0, p_phi0, self._rect(rect)), "rt_filter")
+
+    def tonemap(self, source=IMAGE_COLOR, exposure=1.0, rect=None):
+        self._check(lib().rt_tonemap(self._h, source, exposure, self._rect(rect)), "rt_tonemap")
+
+    def readback(self, image):
+        dt, ch = _IMAGE_DTYPES[image]
+        shape = (self.height, self.width, ch) if ch > 1 else (self.height, self.width)
+        out = np.empty(shape, dt)
+        self._check(lib().rt_readback(self._h, image, out.ctypes.data, out.nbytes), f"rt_readback({image})")
+        return out
+
+    def write_image(self, image, array):
+        dt, _ = _IMAGE_DTYPES[image]
+        a = np.ascontiguousarray(array, dt)
+        self._check(lib().rt_write_image(self._h, image, a.ctypes.data, a.nbytes), f"rt_write_image({image})")
+
+    def readback_rect_device(self, image, rect, device_ptr, nbytes):
+        self._check(lib().rt_readback_rect_device(self._h, image, self._rect(rect), ctypes.c_void_p(device_ptr),
+                                                  nbytes), "rt_readback_rect_device")
+
+    def write_rect_device(self, image, rect, device_ptr, nbytes):
+        self._check(lib().rt_write_rect_device(self._h, image, self._rect(rect), ctypes.c_void_p(device_ptr),
+                                               nbytes), "rt_write_rect_device")
+
+    def counters(self):
+        c = Counters()
+        self._check(lib().rt_counters_read(self._h, ctypes.byref(c)), "rt_counters_read")
+        return c
+
+    def reset_counters(self):
+        self._check(lib().rt_counters_reset(self._h), "rt_counters_reset")
+
+    def profile(self, enable=True):
+        self._check(lib().rt_profile(self._h, int(enable)), "rt_profile")
+
+    def timings(self, reset=False):
+        t = Timings()
+        self._check(lib().rt_timings_read(self._h, ctypes.byref(t), int(reset)), "rt_timings_read")
+        return t
+
+    def sync(self):
+        self._check(lib().rt_sync(self._h), "rt_sync")
+
+    def close(self):
+        if self._h:
+            lib().rt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
