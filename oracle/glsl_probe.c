@@ -3,12 +3,17 @@
  * (binding 1, floats), one work-group.  Used to measure the arithmetic semantics of the GLSL
  * implementation the reference is judged on (operation order of dot/mix/normalize, image
  * format conversions, ...), i.e. to re-assert SURVEY.md Appendix B before trusting a comparison.
- *   usage: glsl_probe shader.comp in.f32 n_out out.f32
+ *   usage: glsl_probe shader.comp[,extra.glsl,...] in.f32 n_out out.f32 [groups_x]
+ * Extra files (e.g. the reference's geometry.glsl / random.glsl, read from where they lie) are
+ * compiled as further compute-shader objects and linked in, the way the reference links its own
+ * program (reference src/ComputeShader.cpp:38-63), so a probe main can call the reference's
+ * functions directly and known-answer vectors come from the reference's own code.
  */
 #include <GL/gl.h>
 #include <GL/glext.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "gl_headless.h"
 
 static char *slurp(const char *p, size_t *n) {
@@ -23,7 +28,8 @@ static char *slurp(const char *p, size_t *n) {
 }
 
 int main(int argc, char **argv) {
-    if (argc != 5) { fprintf(stderr, "usage: %s shader in.f32 n_out out.f32\n", argv[0]); return 2; }
+    if (argc != 5 && argc != 6) { fprintf(stderr, "usage: %s shader[,extra...] in.f32 n_out out.f32 [groups]\n", argv[0]); return 2; }
+    int groups = argc == 6 ? atoi(argv[5]) : 1;
     int rc = glh_init(4, 3);
     if (rc) return rc;
     PFNGLCREATESHADERPROC CreateShader = glh_proc("glCreateShader");
@@ -51,18 +57,22 @@ int main(int argc, char **argv) {
     void (*Finish)(void) = glh_proc("glFinish");
 
     size_t inBytes;
-    char *src = slurp(argv[1], NULL);
     char *in = slurp(argv[2], &inBytes);
     int nOut = atoi(argv[3]);
-    GLuint sh = CreateShader(GL_COMPUTE_SHADER);
-    const char *csrc = src;
-    ShaderSource(sh, 1, &csrc, NULL);
-    CompileShader(sh);
-    GLint ok;
-    GetShaderiv(sh, GL_COMPILE_STATUS, &ok);
-    if (!ok) { char log[4096]; GetShaderInfoLog(sh, sizeof log, NULL, log); fprintf(stderr, "%s\n", log); return 5; }
     GLuint prog = CreateProgram();
-    AttachShader(prog, sh);
+    GLint ok;
+    char *list = strdup(argv[1]);
+    for (char *tok = strtok(list, ","); tok; tok = strtok(NULL, ",")) {
+        char *src = slurp(tok, NULL);
+        GLuint sh = CreateShader(GL_COMPUTE_SHADER);
+        const char *csrc = src;
+        ShaderSource(sh, 1, &csrc, NULL);
+        CompileShader(sh);
+        GetShaderiv(sh, GL_COMPILE_STATUS, &ok);
+        if (!ok) { char log[4096]; GetShaderInfoLog(sh, sizeof log, NULL, log); fprintf(stderr, "%s: %s\n", tok, log); return 5; }
+        AttachShader(prog, sh);
+        free(src);
+    }
     LinkProgram(prog);
     GetProgramiv(prog, GL_LINK_STATUS, &ok);
     if (!ok) { char log[4096]; GetProgramInfoLog(prog, sizeof log, NULL, log); fprintf(stderr, "%s\n", log); return 5; }
@@ -85,7 +95,7 @@ int main(int argc, char **argv) {
     BindImageTexture(0, tex[0], 0, GL_FALSE, 0, GL_READ_WRITE, GL_RGBA16F);
     BindImageTexture(1, tex[1], 0, GL_FALSE, 0, GL_READ_WRITE, GL_RGBA8_SNORM);
     UseProgram(prog);
-    DispatchCompute(1, 1, 1);
+    DispatchCompute(groups, 1, 1);
     MemoryBarrier(GL_ALL_BARRIER_BITS);
     Finish();
     BindBuffer(GL_SHADER_STORAGE_BUFFER, b[1]);

@@ -96,6 +96,7 @@ def trace(scene, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.
     p.max_follows = max_follows
     if rect is not None:
         p.x0, p.y0, p.x1, p.y1 = rect
+    stats_sum = np.zeros((height, width, 4), np.int64)
     for k in range(spp):
         frame = frame0 + k
         p.time = float(np.float32(time0) + np.float32(dtime) * np.float32(frame))
@@ -106,7 +107,8 @@ def trace(scene, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.
             p.oob_seeds[:] = [0.0, 0.0, 0.0]
         L.orc_trace(ctypes.byref(scene.c), ctypes.byref(p), color.ctypes.data, normal.ctypes.data, pos.ctypes.data,
                     tridx.ctypes.data, visits.ctypes.data, stats.ctypes.data)
-    return dict(color=color, normal=normal, pos=pos.view(np.float16), tridx=tridx, visits=visits, stats=stats)
+        stats_sum += stats
+    return dict(stats_sum=stats_sum, color=color, normal=normal, pos=pos.view(np.float16), tridx=tridx, visits=visits, stats=stats)
 
 
 def filter_passes(color, normal, pos, iterations, c_phi0=3.3, n_phi0=1e-2, p_phi0=5.5):

@@ -1,0 +1,263 @@
+"""Parity of the HIP path (through the rt_* C-ABI) on a real MI355X.
+
+Checker: the CPU oracle (oracle/rt_oracle.c, pinned against the reference's shaders on llvmpipe by
+tests/test_oracle_golden.py) and, directly, the committed llvmpipe fixtures under tests/golden/.
+Bar: primary-hit triangle IDs, node-visit counts, snorm8 normals and fp16 positions bit-exact;
+radiance within tests/util.py's stated tolerance; filter within 1 fp16 step (exp differs)."""
+import ctypes
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import assets, hiplib, hostlib, workloads
+from tests.util import GOLDEN, assert_radiance_close, half_ulp_diff, load_npz
+
+pytestmark = pytest.mark.gpu
+
+TRACE = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "trace_*.npz")))
+IDS = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "ids_*.npz")))
+FILTER = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "filter_*.npz")))
+ALL_IMAGES = dict(color=hiplib.IMAGE_COLOR, normal=hiplib.IMAGE_NORMAL, pos=hiplib.IMAGE_POSITION,
+                  tridx=hiplib.IMAGE_TRIDX, visits=hiplib.IMAGE_VISITS, stats=hiplib.IMAGE_STATS)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = hiplib.Context(0)  # raises when there is no GPU or no librt_hip.so: no fallback
+    yield c
+    c.close()
+
+
+def render(ctx, wl, spp, mb, flags=hiplib.FLAG_AUX | hiplib.FLAG_PIXEL_STATS, rect=None, **kw):
+    ctx.upload_scene(wl.buffers)
+    ctx.resize(wl.width, wl.height)
+    ctx.reset_counters()
+    ctx.trace_samples(wl.rays, wl.eye, spp=spp, max_bounces=mb, flags=flags, rect=rect,
+                      num_emitters=wl.num_emitters, **kw)
+    return {k: ctx.readback(v) for k, v in ALL_IMAGES.items()}
+
+
+def oracle_render(wl, spp, mb, **kw):
+    from oracle import orclib
+    return orclib.trace(orclib.Scene(wl.buffers), wl.width, wl.height, wl.rays, wl.eye, spp=spp, max_bounces=mb, **kw)
+
+
+def assert_ids_equal(got, ref):
+    assert np.array_equal(got["tridx"], ref["tridx"])
+    assert np.array_equal(got["visits"], ref["visits"])
+    assert np.array_equal(got["normal"], ref["normal"])
+    assert np.array_equal(got["pos"].view(np.uint16), np.asarray(ref["pos"]).view(np.uint16))
+
+
+@pytest.mark.parametrize("name", TRACE)
+def test_trace_against_llvmpipe_fixture(ctx, name):
+    g = load_npz(name)
+    m = g["meta"]
+    wl = workloads.Workload(m["scene"], m["width"], m["height"])
+    got = render(ctx, wl, m["spp"], m["max_bounces"])
+    assert_ids_equal(got, g)
+    assert (got["stats"][..., 0] != g["stats"][..., 0]).mean() < 5e-3
+    assert_radiance_close(g["color"], got["color"], name)
+
+
+@pytest.mark.parametrize("name", IDS)
+def test_full_size_ids_against_llvmpipe_fixture(ctx, name):
+    """BASELINE.json configs[0..2] at their full sizes: primary-hit ID and visit-count buffers bit-exact."""
+    g = load_npz(name)
+    m = g["meta"]
+    wl = workloads.Workload(m["scene"], m["width"], m["height"])
+    got = render(ctx, wl, 1, 0, flags=hiplib.FLAG_AUX)
+    assert np.array_equal(got["tridx"], g["tridx"].astype(np.int32))
+    assert np.array_equal(got["visits"], g["visits"].astype(np.int32))
+    assert hashlib.sha256(got["tridx"].tobytes()).hexdigest() == m["tridx_sha256"]
+    assert hashlib.sha256(got["visits"].tobytes()).hexdigest() == m["visits_sha256"]
+    assert hashlib.sha256(got["normal"].tobytes()).hexdigest() == m["normal_sha256"]
+    assert hashlib.sha256(got["pos"].tobytes()).hexdigest() == m["pos_sha256"]
+    c = ctx.counters()
+    assert c.rays == m["width"] * m["height"] and c.node_visits == m["visits_sum"] and c.tri_tests == m["tests_sum"]
+
+
+@pytest.mark.parametrize("scene,w,h,spp,mb", [("room", 200, 150, 3, 5), ("scene", 320, 180, 4, 5),
+                                               ("suzanne", 256, 144, 2, 1), ("teapot", 160, 120, 1, 4),
+                                               ("room", 33, 17, 1, 5)])
+def test_trace_against_oracle(ctx, scene, w, h, spp, mb):
+    wl = workloads.Workload(scene, w, h)
+    got = render(ctx, wl, spp, mb)
+    ref = oracle_render(wl, spp, mb)
+    assert_ids_equal(got, ref)
+    assert_radiance_close(ref["color"], got["color"], f"{scene} {w}x{h}")
+    c = ctx.counters()
+    assert c.paths == w * h * spp
+    # counters are the per-pixel statistics summed (here: last sample's image vs. oracle's)
+    assert abs(int(got["stats"][..., 0].sum()) - int(ref["stats"][..., 0].sum())) <= 0.002 * ref["stats"][..., 0].sum()
+
+
+def test_full_size_radiance_and_counters_against_oracle(ctx):
+    """The metric configuration itself (scene.obj 1920x1080 4 spp, 5 bounces) against the oracle."""
+    wl = workloads.Workload("scene", 1920, 1080)
+    got = render(ctx, wl, 4, 5)
+    ref = oracle_render(wl, 4, 5)
+    assert_ids_equal(got, ref)
+    frac, rmse, mean, mx = assert_radiance_close(ref["color"], got["color"], "scene 1080p")
+    print(f"scene 1080p 4spp: outliers {frac:.2e}, RMSE {rmse:.3e}, mean radiance {mean:.3f}, max rel {mx:.2e}")
+
+
+def test_oob_seed_rule_is_a_parameter(ctx):
+    wl = workloads.Workload("room", 64, 48)
+    a = render(ctx, wl, 1, 5, oob="llvmpipe")
+    b = render(ctx, wl, 1, 5, oob="zero")
+    ref = oracle_render(wl, 1, 5, oob="zero")
+    assert_radiance_close(ref["color"], b["color"], "oob zero")
+    assert not np.array_equal(a["color"], b["color"])  # the rule matters from bounce 2 on
+    a1, b1 = render(ctx, wl, 1, 1, oob="llvmpipe"), render(ctx, wl, 1, 1, oob="zero")
+    assert np.array_equal(a1["color"], b1["color"])    # and not before
+
+
+def test_tile_equals_full_frame(ctx):
+    wl = workloads.Workload("room", 96, 80)
+    full = render(ctx, wl, 2, 3)
+    ctx.clear()
+    for rect in [(0, 0, 50, 33), (50, 0, 96, 33), (0, 33, 96, 80)]:  # ragged, not multiples of 16
+        ctx.trace_samples(wl.rays, wl.eye, spp=2, max_bounces=3, flags=hiplib.FLAG_AUX | hiplib.FLAG_PIXEL_STATS,
+                          rect=rect)
+    tiles = {k: ctx.readback(v) for k, v in ALL_IMAGES.items()}
+    for k in full:
+        assert np.array_equal(full[k].view(np.uint8), tiles[k].view(np.uint8)), k
+
+
+def test_outside_tile_untouched(ctx):
+    wl = workloads.Workload("room", 64, 48)
+    ctx.upload_scene(wl.buffers)
+    ctx.resize(64, 48)
+    ctx.trace_samples(wl.rays, wl.eye, spp=1, max_bounces=1, flags=hiplib.FLAG_AUX, rect=(10, 5, 30, 20))
+    col, tri = ctx.readback(hiplib.IMAGE_COLOR), ctx.readback(hiplib.IMAGE_TRIDX)
+    mask = np.zeros((48, 64), bool)
+    mask[5:20, 10:30] = True
+    assert np.all(col[~mask] == 0) and np.all(tri[~mask] == -1) and np.all(col[mask][:, 3] == 1.0)
+    # an empty tile is a no-op
+    ctx.trace_samples(wl.rays, wl.eye, spp=1, max_bounces=1, rect=(7, 7, 7, 9))
+
+
+def test_no_emitters_matches_oracle_nan_behaviour(ctx):
+    # testTable.obj without the harness light: the reference divides by numEmitters = 0
+    s = hostlib.Scene(assets.path("testTable.obj")).build(with_qtable=False)
+    bufs = {k: s.buffer(k) for k in hostlib.ALL_SLOTS}
+    cam = hostlib.auto_camera(s.info())
+    rays = hostlib.camera_rays(width=64, height=48, **cam)
+    ctx.upload_scene(bufs)
+    ctx.resize(64, 48)
+    ctx.trace_samples(rays, cam["eye"], spp=1, max_bounces=2, flags=hiplib.FLAG_AUX, num_emitters=0)
+    got = ctx.readback(hiplib.IMAGE_COLOR)
+    tri = ctx.readback(hiplib.IMAGE_TRIDX)
+    from oracle import orclib
+    ref = orclib.trace(orclib.Scene(bufs), 64, 48, rays, cam["eye"], spp=1, max_bounces=2, num_emitters=0)
+    assert np.array_equal(tri, ref["tridx"]) and (tri >= 0).any()
+    assert np.array_equal(np.isnan(got[..., :3]).any(-1), np.isnan(ref["color"][..., :3]).any(-1))
+    assert np.isnan(got[tri >= 0][:, :3]).any(-1).all()          # every hit pixel is NaN, as in the reference
+    ok = ~np.isnan(ref["color"][..., :3]).any(-1)
+    assert np.array_equal(got[ok], ref["color"][ok])              # sky pixels are exact
+
+
+def test_max_follows_abort(ctx):
+    wl = workloads.Workload("room", 48, 32)
+    got = render(ctx, wl, 1, 1, max_follows=20)
+    ref = oracle_render(wl, 1, 1, max_follows=20)
+    assert_ids_equal(got, ref)
+    assert (got["visits"] == 21).any() and (got["tridx"][got["visits"] == 21] == -1).all()
+    assert_radiance_close(ref["color"], got["color"], "max_follows")
+
+
+@pytest.mark.parametrize("name", FILTER)
+def test_filter_against_llvmpipe_fixture(ctx, name):
+    g = load_npz(name)
+    h, w = g["color"].shape[:2]
+    ctx.resize(w, h)
+    ctx.write_image(hiplib.IMAGE_COLOR, g["color"])
+    ctx.write_image(hiplib.IMAGE_NORMAL, g["normal"])
+    ctx.write_image(hiplib.IMAGE_POSITION, g["pos"].view(np.float16))
+    for it in range(1, g["meta"]["iterations"] + 1):
+        ctx.filter(it)
+        got = ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16)
+        want = g["passes"][it - 1]
+        wf, gf = want.view(np.float16).astype(np.float32), got.view(np.float16).astype(np.float32)
+        assert np.array_equal(np.isnan(wf), np.isnan(gf)), (name, it)
+        ok = ~np.isnan(wf)
+        d = half_ulp_diff(want[ok], got[ok])
+        assert d.max() <= 1 and (d == 0).mean() > 0.995, (name, it, int(d.max()), float((d == 0).mean()))
+
+
+def test_filter_full_size_against_oracle_and_tile_mode(ctx):
+    from oracle import orclib
+    wl = workloads.Workload("scene", 1920, 1080)
+    got = render(ctx, wl, 2, 2, flags=0)
+    ctx.filter(5)
+    full = ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16)
+    want = orclib.filter_passes(got["color"], got["normal"], got["pos"], 5)[-1].view(np.uint16)
+    d = half_ulp_diff(want, full)
+    assert d.max() <= 1 and (d == 0).mean() > 0.995
+    # tile mode: filtering only a strip (with everything traced) reproduces the strip of the full filter,
+    # and strips filtered one by one reproduce the whole frame (what the multi-GPU path relies on)
+    for rect in [(0, 270, 1920, 540), (100, 0, 700, 90), (1800, 1000, 1920, 1080)]:
+        ctx.filter(5, rect=rect)
+        part = ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16)
+        x0, y0, x1, y1 = rect
+        assert np.array_equal(part[y0:y1, x0:x1], full[y0:y1, x0:x1]), rect
+
+
+def test_strip_with_halo_equals_full_frame(ctx):
+    """Trace only strip + halo, filter the strip: equals the same rows of the full frame (multi-GPU contract)."""
+    wl = workloads.Workload("room", 160, 200)
+    render(ctx, wl, 2, 2, flags=0)
+    ctx.filter(4)
+    full = ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16)
+    halo = hiplib.lib().rt_filter_halo(4)
+    assert halo == 1 + 3 + 7 + 15
+    for y0, y1 in [(0, 50), (50, 100), (100, 150), (150, 200)]:
+        ctx.clear()
+        ctx.write_image(hiplib.IMAGE_COLOR, np.full((200, 160, 4), np.nan, np.float32))  # poison what is not traced
+        t0, t1 = max(y0 - halo, 0), min(y1 + halo, 200)
+        ctx.trace_samples(wl.rays, wl.eye, spp=2, max_bounces=2, rect=(0, t0, 160, t1))
+        ctx.filter(4, rect=(0, y0, 160, y1))
+        part = ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16)
+        assert np.array_equal(part[y0:y1], full[y0:y1]), (y0, y1)
+
+
+def test_tonemap_against_oracle(ctx):
+    from oracle import orclib
+    wl = workloads.Workload("room", 64, 48)
+    got = render(ctx, wl, 1, 2, flags=0)
+    ctx.tonemap(hiplib.IMAGE_COLOR, 1.0)
+    ldr = ctx.readback(hiplib.IMAGE_LDR)
+    want = np.zeros((48, 64, 4), np.uint8)
+    col = np.ascontiguousarray(got["color"])
+    orclib.lib().orc_tonemap(64 * 48, col.ctypes.data, 1, 1.0, want.ctypes.data)
+    assert np.abs(ldr.astype(int) - want.astype(int)).max() <= 1 and (ldr == want).mean() > 0.99
+    assert np.all(ldr[..., 3] == 255)
+
+
+def test_error_paths(ctx):
+    L = hiplib.lib()
+    assert L.rt_upload(ctx._h, 3, ctypes.c_char_p(b"x" * 47), 47) == -1          # not a multiple of 48
+    bad = np.zeros(1, hostlib.NODE_DTYPE)
+    bad["hitNext"], bad["missNext"] = 5, -1                                       # link out of range
+    assert L.rt_upload(ctx._h, 3, bad.ctypes.data, 48) == -6
+    assert b"link out of range" in L.rt_last_error(ctx._h)
+    p = hiplib.make_params(np.zeros((4, 3)), (0, 0, 0), 1.25, 0.0, 5, 0)
+    p.size = 12
+    assert L.rt_trace(ctx._h, ctypes.byref(p), None) == -1
+    p = hiplib.make_params(np.zeros((4, 3)), (0, 0, 0), 1.25, 0.0, 5, 0, kernel=99)
+    ctx.resize(16, 16)
+    assert L.rt_trace(ctx._h, ctypes.byref(p), None) == -1
+    r = hiplib.Rect(0, 0, 17, 16)
+    p = hiplib.make_params(np.zeros((4, 3)), (0, 0, 0), 1.25, 0.0, 5, 0)
+    assert L.rt_trace(ctx._h, ctypes.byref(p), ctypes.byref(r)) == -1            # tile outside the image
+    assert L.rt_filter(ctx._h, 7, 3.3, 0.01, 5.5, None) == -1                     # step beyond the LDS tile
+    # a leaf that references triangles beyond the uploaded stream is refused at launch
+    wl = workloads.Workload("room", 16, 16)
+    ctx.upload_scene(wl.buffers)
+    ctx.upload(4, wl.buffers[4][: 128 * 100])
+    assert L.rt_trace(ctx._h, ctypes.byref(p), None) == -6
+    ctx.upload_scene(wl.buffers)
