@@ -14,7 +14,7 @@
 #include "rt_device.h"
 
 hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace_params &p, const rt_rect &tile,
-                          RtCountersDev *counters, hipStream_t stream);
+                          int xcdRemap, RtCountersDev *counters, hipStream_t stream);
 hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const uint32_t *normal, const uint2 *pos,
                           uint2 *out, int W, int H, const rt_rect &rect, float c_phi, float n_phi, float p_phi,
                           int step, hipStream_t stream);
@@ -413,7 +413,10 @@ int rt_trace(rt_ctx *c, const rt_trace_params *p, const rt_rect *tile) {
         img.width = c->width;
         img.height = c->height;
         SpanGuard span(c, TK_TRACE);
-        hipError_t e = rtLaunchTrace3(sc, img, *p, r, (RtCountersDev *)c->counters.p, c->stream);
+        // scene bytes the traversal touches vs. one XCD's 4 MiB L2
+        const size_t hot = c->boxes.bytes + c->leaves.bytes + c->tris48.bytes;
+        const int xcdRemap = hot > (size_t)3 * 1024 * 1024;
+        hipError_t e = rtLaunchTrace3(sc, img, *p, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream);
         span.end();
         if (e != hipSuccess) return hipFail(c, e, "trace3 launch");
         return RT_OK;

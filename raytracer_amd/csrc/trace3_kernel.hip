@@ -189,6 +189,10 @@ __device__ __forceinline__ float randomTriangleAreaDirectionPDF(f3 p, const Ligh
 // intersectGeometry's loop (trace3.cs:226-269) + intersectTriangles (:172-186).
 // Returns false when the MAX_FOLLOWS abort was taken (trace3.cs:228-234).
 __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origin, f3 dir, f3 invdir, Hit &hit) {
+    // "while-while" form: every lane first walks nodes until it holds a leaf whose box it entered
+    // (or runs out of nodes), then the wave tests leaf triangles together.  Per lane the sequence of
+    // node visits and triangle tests is exactly the reference's; only the interleaving across the
+    // lanes of a wave differs, which keeps the 64 lanes in the same loop most of the time.
     int next = 0;
     float nearest = __builtin_inff();
     int iterations = 0;
@@ -197,59 +201,61 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
     hit.t = hit.u = hit.v = 0.0f;
     bool ok = true;
     const bool ltx = invdir.x < 0.0f, lty = invdir.y < 0.0f, ltz = invdir.z < 0.0f;
-    while (next != -1) {
-        iterations++;
-        if (iterations > c.maxFollows) {
-            ok = false;
-            hit.tridx = -1;
-            break;
-        }
-        if ((unsigned)next >= (unsigned)sc.numNodes) { // cannot happen after upload validation
-            next = -1;
-            break;
-        }
-        const float4 b0 = sc.boxes[2 * next], b1 = sc.boxes[2 * next + 1];
-        const int hitNext = __float_as_int(b0.w), missNext = __float_as_int(b1.w);
-        // intersectBox, geometry.glsl:66-76
-        const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
-                    m1z = (b0.z - origin.z) * invdir.z;
-        const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
-                    m2z = (b1.z - origin.z) * invdir.z;
-        const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
-        const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
-        const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f;
-        if (!boxHit || mint > nearest) {
-            next = missNext;
-            continue;
-        }
-        const int2 leaf = sc.leaves[next];
-        if (leaf.y > 0) {
-            for (int i = leaf.x; i < leaf.x + leaf.y; i++) {
-                const float4 a0 = sc.tris48[3 * i], a1 = sc.tris48[3 * i + 1], a2 = sc.tris48[3 * i + 2];
-                tests++;
-                // intersectTriangle, geometry.glsl:31-51 (e1, e2 pre-subtracted at upload: same fp32 values)
-                const f3 v0 = xyz(a0), e1 = xyz(a1), e2 = xyz(a2);
-                const f3 pvec = cross(dir, e2);
-                const float det = dot(e1, pvec);
-                if (det < 0.0f) continue;
-                const f3 tvec = origin - v0;
-                const float u = dot(tvec, pvec);
-                if (u < 0.0f || u > det) continue;
-                const f3 qvec = cross(tvec, e1);
-                const float v = dot(dir, qvec);
-                if (v < 0.0f || (u + v) > det) continue;
-                const float invDet = 1.0f / det;
-                const float t = dot(e2, qvec) * invDet;
-                if (t >= 0.0f && t < nearest) {
-                    nearest = t;
-                    hit.t = t;
-                    hit.u = u * invDet;
-                    hit.v = v * invDet;
-                    hit.tridx = i;
-                }
+    for (;;) {
+        int leafFirst = 0, leafCount = 0;
+        while (next != -1 && leafCount == 0) {
+            iterations++;
+            if (iterations > c.maxFollows) { // trace3.cs:228-234
+                ok = false;
+                hit.tridx = -1;
+                next = -1;
+                break;
+            }
+            const float4 b0 = sc.boxes[2 * next], b1 = sc.boxes[2 * next + 1];
+            const int hitNext = __float_as_int(b0.w), missNext = __float_as_int(b1.w);
+            // intersectBox, geometry.glsl:66-76
+            const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
+                        m1z = (b0.z - origin.z) * invdir.z;
+            const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
+                        m2z = (b1.z - origin.z) * invdir.z;
+            const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
+            const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
+            const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f;
+            if (!boxHit || mint > nearest) {
+                next = missNext;
+            } else {
+                const int2 leaf = sc.leaves[next];
+                leafFirst = leaf.x;
+                leafCount = leaf.y; // 0 for inner nodes: keep walking
+                next = hitNext;
             }
         }
-        next = hitNext;
+        if (leafCount <= 0) break;
+        const int leafEnd = leafFirst + leafCount;
+        for (int i = leafFirst; i < leafEnd; i++) {
+            const float4 a0 = sc.tris48[3 * i], a1 = sc.tris48[3 * i + 1], a2 = sc.tris48[3 * i + 2];
+            tests++;
+            // intersectTriangle, geometry.glsl:31-51 (e1, e2 pre-subtracted at upload: same fp32 values)
+            const f3 v0 = xyz(a0), e1 = xyz(a1), e2 = xyz(a2);
+            const f3 pvec = cross(dir, e2);
+            const float det = dot(e1, pvec);
+            if (det < 0.0f) continue;
+            const f3 tvec = origin - v0;
+            const float u = dot(tvec, pvec);
+            if (u < 0.0f || u > det) continue;
+            const f3 qvec = cross(tvec, e1);
+            const float v = dot(dir, qvec);
+            if (v < 0.0f || (u + v) > det) continue;
+            const float invDet = 1.0f / det;
+            const float t = dot(e2, qvec) * invDet;
+            if (t >= 0.0f && t < nearest) { // intersectTriangles, trace3.cs:177: strict <, lowest index wins ties
+                nearest = t;
+                hit.t = t;
+                hit.u = u * invDet;
+                hit.v = v * invDet;
+                hit.tridx = i;
+            }
+        }
     }
     c.lastIterations = iterations;
     c.rays++;
@@ -387,13 +393,17 @@ __device__ __forceinline__ void waveAdd(unsigned long long *dst, unsigned v) {
 } // namespace
 
 __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img, rt_trace_params p, rt_rect tile,
-                                                        int tilesX, int tilesY, RtCountersDev *counters) {
-    // XCD-aware tile order: blocks b, b+8, b+16, ... share an XCD and get consecutive tiles
+                                                        int tilesX, int tilesY, int xcdRemap,
+                                                        RtCountersDev *counters) {
+    // Tile order.  Blocks b, b+8, b+16, ... share an XCD (and its private L2).  When the scene is larger
+    // than an L2, those blocks get consecutive tiles so that each L2 caches one screen region's part of
+    // the BVH; when the whole scene fits in every L2 the plain order is kept, which spreads the
+    // expensive tiles (the ones that see geometry) over all eight XCDs.
     const int nblocks = gridDim.x;
     const int b = blockIdx.x;
-    const int perXcd = (nblocks + 7) / 8;
-    int t = (b % 8) * perXcd + b / 8;
-    const bool live = t < tilesX * tilesY && (b / 8) < perXcd;
+    const int perXcd = nblocks / 8;
+    const int t = xcdRemap ? (b % 8) * perXcd + b / 8 : b;
+    const bool live = t < tilesX * tilesY;
     // 8x8 pixels per wave, 2x2 waves per block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = (lane & 7) + 8 * (wave & 1), ly = (lane >> 3) + 8 * (wave >> 1);
@@ -499,13 +509,13 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
 
 // Host-side launch used by rt_launcher.hip
 hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace_params &p, const rt_rect &tile,
-                          RtCountersDev *counters, hipStream_t stream) {
+                          int xcdRemap, RtCountersDev *counters, hipStream_t stream) {
     const int tw = tile.x1 - tile.x0, th = tile.y1 - tile.y0;
     if (tw <= 0 || th <= 0) return hipSuccess;
     const int tilesX = (tw + 15) / 16, tilesY = (th + 15) / 16;
     const int ntiles = tilesX * tilesY;
     const int nblocks = ((ntiles + 7) / 8) * 8; // multiple of 8 so that the XCD re-map is a bijection
     hipLaunchKernelGGL(rt_trace3_kernel, dim3(nblocks), dim3(256), 0, stream, sc, img, p, tile, tilesX, tilesY,
-                       counters);
+                       xcdRemap, counters);
     return hipGetLastError();
 }
