@@ -79,7 +79,8 @@ enum rt_kernel {
 enum rt_flags {
     RT_FLAG_AUX = 1,       /* also write primary-hit triangle index + node-visit count images */
     RT_FLAG_PIXEL_STATS = 2, /* also write per-pixel (traversals, node visits, triangle tests, 0)  */
-    RT_FLAG_NO_COUNTERS = 4  /* skip the global ray / visit / test counters                      */
+    RT_FLAG_NO_COUNTERS = 4, /* skip the global ray / visit / test counters                      */
+    RT_FLAG_PER_PIXEL_KERNEL = 8 /* run the one-lane-per-path kernel instead of the wavefront pipeline (same results) */
 };
 
 typedef struct rt_rect {
@@ -152,6 +153,13 @@ int rt_clear(rt_ctx *ctx);
 
 /* One dispatch over `tile` (NULL = whole image).  Pixels outside the tile are left untouched. */
 int rt_trace(rt_ctx *ctx, const rt_trace_params *params, const rt_rect *tile);
+
+/* n successive dispatches in one call: exactly the images that n calls of rt_trace(params[0]),
+ * ..., rt_trace(params[n-1]) produce (sample k blended with params[k].blendFactor, in order), but the
+ * n samples are traced concurrently.  Only time, blendFactor, frameIndex and oobSeeds may differ
+ * between the entries; n <= 16.  The reference has no counterpart: its main loop issues one dispatch
+ * per frame (reference src/main.cpp:67-69); a headless renderer that wants k spp per frame calls this. */
+int rt_trace_batch(rt_ctx *ctx, const rt_trace_params *params, int n, const rt_rect *tile);
 
 /* Filter::filter: `iterations` à-trous passes over the colour image using the normal / position
  * images.  With a tile, every pass covers the tile grown by the step widths of the passes that

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "rt_device.h"
+#include "wavefront.h"
 
 hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace_params &p, const rt_rect &tile,
                           int xcdRemap, RtCountersDev *counters, hipStream_t stream);
@@ -53,6 +54,10 @@ struct rt_ctx {
     int width = 0, height = 0;
     DevBuf color, normal, pos, filt[2], tridx, visits, stats, ldr;
     int filteredIndex = -1; // which of filt[] holds the result of the last rt_filter
+
+    // wavefront path tracer state (wavefront.h), grown on demand
+    DevBuf wfState[8], wfRay[4], wfQueue[2], wfCounts, wfRadiance;
+    size_t wfCapacity = 0, wfRadianceSlots = 0;
 
     DevBuf counters;
     bool profile = false;
@@ -242,7 +247,10 @@ void rt_destroy(rt_ctx *c) {
     }
     for (hipEvent_t e : c->eventPool) (void)hipEventDestroy(e);
     DevBuf *all[] = {&c->boxes, &c->leaves, &c->tris48, &c->tris128, &c->mtls, &c->emitters, &c->color, &c->normal,
-                     &c->pos, &c->filt[0], &c->filt[1], &c->tridx, &c->visits, &c->stats, &c->ldr, &c->counters};
+                     &c->pos, &c->filt[0], &c->filt[1], &c->tridx, &c->visits, &c->stats, &c->ldr, &c->counters,
+                     &c->wfQueue[0], &c->wfQueue[1], &c->wfCounts, &c->wfRadiance};
+    for (DevBuf &b : c->wfState) releaseBuf(b);
+    for (DevBuf &b : c->wfRay) releaseBuf(b);
     for (DevBuf *b : all) releaseBuf(*b);
     for (DevBuf &b : c->raw) releaseBuf(b);
     for (DevBuf &b : c->tables) releaseBuf(b);
@@ -377,9 +385,90 @@ int rt_resize(rt_ctx *c, int width, int height) {
     return rt_clear(c);
 }
 
-int rt_trace(rt_ctx *c, const rt_trace_params *p, const rt_rect *tile) {
-    if (!c || !p) return RT_EINVAL;
-    if (p->size != sizeof(rt_trace_params)) return fail(c, RT_EINVAL, "rt_trace: params.size mismatch");
+namespace {
+
+void fillScene(const rt_ctx *c, RtScene &sc, RtImages &img) {
+    sc.boxes = (const float4 *)c->boxes.p;
+    sc.leaves = (const int2 *)c->leaves.p;
+    sc.tris48 = (const float4 *)c->tris48.p;
+    sc.tris128 = (const RtTri128 *)c->tris128.p;
+    sc.mtls = (const RtMtl *)c->mtls.p;
+    sc.emitters = (const RtTri128 *)c->emitters.p;
+    sc.numNodes = c->numNodes;
+    sc.numTris = c->numTris;
+    sc.numMtls = c->numMtls;
+    sc.numEmitters = c->emitters.p ? c->numEmitters : 0;
+    img.color = (float4 *)c->color.p;
+    img.normal = (uint32_t *)c->normal.p;
+    img.pos = (uint2 *)c->pos.p;
+    img.tridx = (int *)c->tridx.p;
+    img.visits = (int *)c->visits.p;
+    img.stats = (int4 *)c->stats.p;
+    img.width = c->width;
+    img.height = c->height;
+}
+
+// Device memory of the wavefront pipeline for `capacity` path slots and `radianceSlots` (sample, pixel) pairs.
+int ensureWavefront(rt_ctx *c, size_t capacity, size_t radianceSlots, WfBuffers &wf) {
+    int r;
+    if (capacity > c->wfCapacity) {
+        // grow with some slack so that tiles of slightly different sizes do not re-allocate
+        const size_t cap = capacity + capacity / 16;
+        for (int k = 0; k < 6; ++k)
+            if ((r = ensure(c, c->wfState[k], cap * 16))) return r;
+        if ((r = ensure(c, c->wfState[6], cap * 8))) return r;  // pixSample
+        if ((r = ensure(c, c->wfState[7], cap * 16))) return r; // pathStats
+        if ((r = ensure(c, c->wfRay[0], 3 * cap * 16)) || (r = ensure(c, c->wfRay[1], 3 * cap * 16)) ||
+            (r = ensure(c, c->wfRay[2], 3 * cap * 16)) || (r = ensure(c, c->wfRay[3], 3 * cap * 8)))
+            return r;
+        if ((r = ensure(c, c->wfQueue[0], cap * 4)) || (r = ensure(c, c->wfQueue[1], cap * 4))) return r;
+        c->wfCapacity = cap;
+    }
+    if ((r = ensure(c, c->wfCounts, 64 * sizeof(int)))) return r;
+    if (radianceSlots > c->wfRadianceSlots) {
+        if ((r = ensure(c, c->wfRadiance, radianceSlots * 16))) return r;
+        c->wfRadianceSlots = radianceSlots;
+    }
+    wf.L_seed = (float4 *)c->wfState[0].p;
+    wf.beta = (float4 *)c->wfState[1].p;
+    wf.betaOld = (float4 *)c->wfState[2].p;
+    wf.f1w1 = (float4 *)c->wfState[3].p;
+    wf.f2w2 = (float4 *)c->wfState[4].p;
+    wf.pdfs = (float4 *)c->wfState[5].p;
+    wf.pixSample = (uint2 *)c->wfState[6].p;
+    wf.pathStats = (int4 *)c->wfState[7].p;
+    wf.rayO = (float4 *)c->wfRay[0].p;
+    wf.rayD = (float4 *)c->wfRay[1].p;
+    wf.rayHit = (int4 *)c->wfRay[2].p;
+    wf.rayWork = (int2 *)c->wfRay[3].p;
+    wf.queue[0] = (int *)c->wfQueue[0].p;
+    wf.queue[1] = (int *)c->wfQueue[1].p;
+    wf.counts = (int *)c->wfCounts.p;
+    wf.radiance = (float4 *)c->wfRadiance.p;
+    wf.capacity = (int)c->wfCapacity;
+    return RT_OK;
+}
+
+bool sameExceptPerSample(const rt_trace_params &a, const rt_trace_params &b) {
+    rt_trace_params x = a, y = b;
+    x.time = y.time = 0;
+    x.blendFactor = y.blendFactor = 0;
+    x.frameIndex = y.frameIndex = 0;
+    for (int k = 0; k < 3; ++k) x.oobSeeds[k] = y.oobSeeds[k] = 0;
+    return std::memcmp(&x, &y, sizeof x) == 0;
+}
+
+} // namespace
+
+int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rect *tile) {
+    if (!c || !params) return RT_EINVAL;
+    if (n < 1 || n > WF_MAX_BATCH) return fail(c, RT_EINVAL, "rt_trace_batch: n must be 1..16");
+    const rt_trace_params *p = &params[0];
+    for (int k = 0; k < n; ++k) {
+        if (params[k].size != sizeof(rt_trace_params)) return fail(c, RT_EINVAL, "rt_trace: params.size mismatch");
+        if (k && !sameExceptPerSample(params[0], params[k]))
+            return fail(c, RT_EINVAL, "rt_trace_batch: entries may differ only in time, blendFactor, frameIndex, oobSeeds");
+    }
     if (!c->color.p) return fail(c, RT_ESTATE, "rt_trace: no images (call rt_resize)");
     const rt_rect r = tile ? *tile : fullRect(c);
     if (!rectOk(c, r)) return fail(c, RT_EINVAL, "rt_trace: tile outside the image");
@@ -393,38 +482,58 @@ int rt_trace(rt_ctx *c, const rt_trace_params *p, const rt_rect *tile) {
         if (c->maxTriEnd > c->numTris)
             return fail(c, RT_ECORRUPT, "rt_trace: a leaf references triangles beyond the uploaded triangle stream");
         RtScene sc;
-        sc.boxes = (const float4 *)c->boxes.p;
-        sc.leaves = (const int2 *)c->leaves.p;
-        sc.tris48 = (const float4 *)c->tris48.p;
-        sc.tris128 = (const RtTri128 *)c->tris128.p;
-        sc.mtls = (const RtMtl *)c->mtls.p;
-        sc.emitters = (const RtTri128 *)c->emitters.p;
-        sc.numNodes = c->numNodes;
-        sc.numTris = c->numTris;
-        sc.numMtls = c->numMtls;
-        sc.numEmitters = c->emitters.p ? c->numEmitters : 0;
         RtImages img;
-        img.color = (float4 *)c->color.p;
-        img.normal = (uint32_t *)c->normal.p;
-        img.pos = (uint2 *)c->pos.p;
-        img.tridx = (int *)c->tridx.p;
-        img.visits = (int *)c->visits.p;
-        img.stats = (int4 *)c->stats.p;
-        img.width = c->width;
-        img.height = c->height;
-        SpanGuard span(c, TK_TRACE);
+        fillScene(c, sc, img);
         // scene bytes the traversal touches vs. one XCD's 4 MiB L2
         const size_t hot = c->boxes.bytes + c->leaves.bytes + c->tris48.bytes;
         const int xcdRemap = hot > (size_t)3 * 1024 * 1024;
-        hipError_t e = rtLaunchTrace3(sc, img, *p, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream);
+        const size_t tilePixels = (size_t)(r.x1 - r.x0) * (size_t)(r.y1 - r.y0);
+        if (tilePixels == 0) return RT_OK;
+        const bool perPixel = (p->flags & RT_FLAG_PER_PIXEL_KERNEL) || p->maxBounces > 30 ||
+                              tilePixels * (size_t)n > ((size_t)1 << 30);
+        if (perPixel) {
+            for (int k = 0; k < n; ++k) {
+                SpanGuard span(c, TK_TRACE);
+                hipError_t e = rtLaunchTrace3(sc, img, params[k], r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream);
+                span.end();
+                if (e != hipSuccess) return hipFail(c, e, "trace3 launch");
+            }
+            return RT_OK;
+        }
+        WfBuffers wf;
+        if ((rc = ensureWavefront(c, tilePixels * (size_t)n, tilePixels * (size_t)n, wf))) return rc;
+        wf.tilePixels = (int)tilePixels;
+        WfParams wp;
+        std::memset(&wp, 0, sizeof wp);
+        std::memcpy(wp.eye, p->eye, sizeof wp.eye);
+        std::memcpy(wp.ray00, p->ray00, sizeof wp.ray00);
+        std::memcpy(wp.ray01, p->ray01, sizeof wp.ray01);
+        std::memcpy(wp.ray10, p->ray10, sizeof wp.ray10);
+        std::memcpy(wp.ray11, p->ray11, sizeof wp.ray11);
+        wp.maxBounces = p->maxBounces;
+        wp.numEmitters = p->numEmitters;
+        wp.maxFollows = p->maxFollows > 0 ? p->maxFollows : 1000;
+        wp.flags = p->flags;
+        wp.batch = n;
+        for (int k = 0; k < n; ++k) {
+            wp.s[k].time = params[k].time;
+            wp.s[k].blendFactor = params[k].blendFactor;
+            wp.s[k].oob0 = params[k].oobSeeds[0];
+            wp.s[k].oob1 = params[k].oobSeeds[1];
+            wp.s[k].oob2 = params[k].oobSeeds[2];
+        }
+        SpanGuard span(c, TK_TRACE);
+        hipError_t e = rtLaunchWavefront(sc, img, wp, wf, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream);
         span.end();
-        if (e != hipSuccess) return hipFail(c, e, "trace3 launch");
+        if (e != hipSuccess) return hipFail(c, e, "wavefront launch");
         return RT_OK;
     }
     default:
         return fail(c, RT_EINVAL, "rt_trace: kernel " + std::to_string(p->kernel) + " is not available in this build");
     }
 }
+
+int rt_trace(rt_ctx *c, const rt_trace_params *p, const rt_rect *tile) { return rt_trace_batch(c, p, 1, tile); }
 
 int rt_filter_halo(int iterations) {
     int h = 0;

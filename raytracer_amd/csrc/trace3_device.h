@@ -1,0 +1,433 @@
+// trace3_device.h — device functions of the live trace path, shared by the per-pixel kernel
+// (trace3_kernel.hip) and the wavefront kernels (wavefront.hip).  Each function cites the lines of
+// reference src/shaders/{trace3.cs, geometry.glsl, random.glsl} it computes; arithmetic is fp32 in the
+// operation order the reference's oracle platform uses (see rt_device.h).
+#ifndef RT_TRACE3_DEVICE_H
+#define RT_TRACE3_DEVICE_H
+
+#include "rt_device.h"
+
+namespace {
+
+#define PI_F 3.14159274101257324f      // float(3.14159265359) == radians(180.0)
+#define TWO_PI_F 6.28318548202514648f  // float(6.28318530718) == 2 * PI
+#define ONE_OVER_PI_T3 (1.0f / PI_F)   // trace3.cs:34
+#define ONE_OVER_2PI_T3 (1.0f / TWO_PI_F)
+#define EPSILON_F 0.0001f
+#define SPECULARITY 0.5f
+
+struct PathCtx {
+    int px, py;
+    float time;
+    int seed;
+    float oob0, oob1, oob2;
+    int maxFollows;
+    // counters
+    unsigned rays, visits, tests, shaded;
+    int lastIterations;
+};
+
+struct Hit {
+    int tridx;
+    float t, u, v;
+};
+
+struct Surface { // surfaceInteraction, trace3.cs:111-119
+    int tridx;
+    int matidx;
+    f3 normal, point;
+};
+
+// ---------------------------------------------------------------- random.glsl
+__device__ __forceinline__ uint32_t hash3(uint32_t x, uint32_t y, uint32_t z) { // random.glsl:53-66
+    x += x >> 11;
+    x ^= x << 7;
+    x += y;
+    x ^= x << 3;
+    x += z ^ (x >> 14);
+    x ^= x << 6;
+    x += x >> 15;
+    x ^= x << 5;
+    x += x >> 12;
+    x ^= x << 9;
+    return x;
+}
+__device__ __forceinline__ float random3(float a, float b, float c) { // random.glsl:68-75
+    uint32_t h = hash3(__float_as_uint(a), __float_as_uint(b), __float_as_uint(c));
+    return __uint_as_float((h & 0x007FFFFFu) | 0x3F800000u) - 1.0f;
+}
+
+// rand_seeds, trace3.cs:280; negative indices read the caller-supplied values (rt_launcher.h)
+__device__ __forceinline__ float seedAt(const PathCtx &c, int i) {
+    float r;
+    switch (i) {
+    case 0: r = 0.0f; break;
+    case 1: r = 1.1f; break;
+    case 2: r = 0.3f; break;
+    case 3: r = 3.3f; break;
+    case 4: r = 0.6f; break;
+    case 5: r = 4.5f; break;
+    case 6: r = 2.4f; break;
+    case 7: r = 0.1f; break;
+    case 8: r = 1.7f; break;
+    case 9: r = 4.7f; break;
+    case 10: r = 1.9f; break;
+    case 11: r = 2.6f; break;
+    case 12: r = 4.8f; break;
+    case -1: r = c.oob0; break;
+    case -2: r = c.oob1; break;
+    case -3: r = c.oob2; break;
+    default: r = 0.0f; break;
+    }
+    return r;
+}
+__device__ __forceinline__ float rnd(const PathCtx &c, int s, int idx) {
+    return random3((float)(c.px + s), (float)(c.py + s), c.time + seedAt(c, idx));
+}
+__device__ __forceinline__ float2 randvec2(PathCtx &c, int s) { // trace3.cs:283-288
+    c.seed = (c.seed + 2) % 13;
+    return make_float2(rnd(c, s, c.seed - 2), rnd(c, s, c.seed - 1));
+}
+__device__ __forceinline__ f3 randvec3(PathCtx &c, int s) { // trace3.cs:290-296
+    c.seed = (c.seed + 3) % 13;
+    return F3(rnd(c, s, c.seed - 3), rnd(c, s, c.seed - 2), rnd(c, s, c.seed - 1));
+}
+__device__ __forceinline__ float randfloat(PathCtx &c, int s) { // trace3.cs:298-301
+    c.seed = (c.seed + 1) % 13;
+    return rnd(c, s, c.seed - 1);
+}
+
+__device__ __forceinline__ f3 ortho(f3 v) { // random.glsl:35-38
+    return normalize(fabsf(v.x) > fabsf(v.z) ? F3(-v.y, v.x, 0.0f) : F3(0.0f, -v.z, v.y));
+}
+__device__ __forceinline__ f3 around(f3 v, f3 z) { // random.glsl:86-90
+    f3 t = ortho(z), b = cross(z, t);
+    return (t * v.x + b * v.y) + z * v.z;
+}
+__device__ __forceinline__ f3 isotropic(float rp, float c) { // random.glsl:92-96
+    float p = TWO_PI_F * rp, s = sqrtf(1.0f - c * c);
+    return F3(cosf(p) * s, sinf(p) * s, c);
+}
+// random.glsl:98-101 (its ONE_OVER_2PI expands to 1.0/(2 * PI))
+__device__ __forceinline__ f3 randomHemispherePoint(f3 n, float rx, float ry, float &pdf) {
+    pdf = 1.0f / TWO_PI_F;
+    return around(isotropic(rx, ry), n);
+}
+// random.glsl:120-124 (`c * ONE_OVER_PI` expands to c * 1.0/PI, a division)
+__device__ __forceinline__ f3 randomCosineWeightedHemispherePoint(f3 n, float rx, float ry, float &pdf) {
+    float c = sqrtf(ry);
+    pdf = c / PI_F;
+    return around(isotropic(rx, c), n);
+}
+__device__ __forceinline__ float randomCosineWeightedHemispherePDF(f3 n, f3 v) { // random.glsl:126-129
+    return fmaxf(0.0f, dot(n, v)) / PI_F;
+}
+__device__ __forceinline__ f3 randomPhongWeightedHemispherePoint(f3 r, float a, float rx, float ry, float &pdf) {
+    float ai = 1.0f / (a + 1.0f); // random.glsl:131-135
+    pdf = (a + 1.0f) * powf(ry, a * ai) / TWO_PI_F;
+    return around(isotropic(rx, powf(ry, ai)), r);
+}
+__device__ __forceinline__ float randomPhongWeightedHemispherePDF(f3 r, float a, f3 v) { // random.glsl:137-142
+    if (dot(r, v) < 0.0f) return 0.0f;
+    return (a + 1.0f) * powf(fmaxf(0.0f, dot(r, v)), a) / TWO_PI_F;
+}
+
+struct LightTri { // the fields of an emitter record that sampling and visible() consume
+    f3 v0, v1, v2, n0, n1, n2;
+    int mtlIndex;
+};
+
+// random.glsl:169-180
+__device__ __forceinline__ f3 randomTriangleAreaDirection(f3 p, const LightTri &t, float rx, float ry, float &pdf) {
+    float one_minus_u = sqrtf(rx);
+    float uvx = 1 - one_minus_u, uvy = ry * one_minus_u;
+    f3 s = (t.v0 * (1 - uvx - uvy) + t.v1 * uvx) + t.v2 * uvy;
+    f3 sp = p - s;
+    float d2 = dot(sp, sp);
+    f3 d = sp * rsq(d2);
+    f3 e1 = t.v1 - t.v0, e2 = t.v2 - t.v0;
+    pdf = d2 / fmaxf(0.0f, fabsf(dot(d, cross(e1, e2) * 0.5f)));
+    return -d;
+}
+// random.glsl:182-209
+__device__ __forceinline__ bool inTri(f3 p, const LightTri &t) {
+    f3 e1 = t.v1 - t.v0, e2 = t.v2 - t.v0;
+    f3 n = cross(e1, e2);
+    f3 c = cross(e1, p - t.v0);
+    if (dot(n, c) < 0) return false;
+    c = cross(e2 - e1, p - t.v1);
+    if (dot(n, c) < 0) return false;
+    c = cross(-e2, p - t.v2);
+    if (dot(n, c) < 0) return false;
+    return true;
+}
+// random.glsl:211-219
+__device__ __forceinline__ float randomTriangleAreaDirectionPDF(f3 p, const LightTri &tri, f3 v) {
+    f3 n = cross(tri.v1 - tri.v0, tri.v2 - tri.v0);
+    float den = dot(n, v), t = dot(tri.v0 - p, n) / den;
+    f3 s = p + v * t, sp = p - s;
+    float len2 = dot(sp, sp);
+    f3 d = sp * rsq(len2);
+    float flag = (den < 0.0f && t > 0.0f && inTri(s, tri)) ? 1.0f : 0.0f;
+    return flag * len2 / fabsf(dot(d, n));
+}
+
+// ---------------------------------------------------------------- traversal
+// intersectGeometry's loop (trace3.cs:226-269) + intersectTriangles (:172-186).
+// Returns false when the MAX_FOLLOWS abort was taken (trace3.cs:228-234).
+__device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origin, f3 dir, f3 invdir, Hit &hit) {
+    // "while-while" form: every lane first walks nodes until it holds a leaf whose box it entered
+    // (or runs out of nodes), then the wave tests leaf triangles together.  Per lane the sequence of
+    // node visits and triangle tests is exactly the reference's; only the interleaving across the
+    // lanes of a wave differs, which keeps the 64 lanes in the same loop most of the time.
+    int next = 0;
+    float nearest = __builtin_inff();
+    int iterations = 0;
+    unsigned tests = 0;
+    hit.tridx = -1;
+    hit.t = hit.u = hit.v = 0.0f;
+    bool ok = true;
+    const bool ltx = invdir.x < 0.0f, lty = invdir.y < 0.0f, ltz = invdir.z < 0.0f;
+    for (;;) {
+        int leafFirst = 0, leafCount = 0;
+        while (next != -1 && leafCount == 0) {
+            iterations++;
+            if (iterations > c.maxFollows) { // trace3.cs:228-234
+                ok = false;
+                hit.tridx = -1;
+                next = -1;
+                break;
+            }
+            const float4 b0 = sc.boxes[2 * next], b1 = sc.boxes[2 * next + 1];
+            const int hitNext = __float_as_int(b0.w), missNext = __float_as_int(b1.w);
+            // intersectBox, geometry.glsl:66-76
+            const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
+                        m1z = (b0.z - origin.z) * invdir.z;
+            const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
+                        m2z = (b1.z - origin.z) * invdir.z;
+            const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
+            const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
+            const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f;
+            if (!boxHit || mint > nearest) {
+                next = missNext;
+            } else {
+                const int2 leaf = sc.leaves[next];
+                leafFirst = leaf.x;
+                leafCount = leaf.y; // 0 for inner nodes: keep walking
+                next = hitNext;
+            }
+        }
+        if (leafCount <= 0) break;
+        const int leafEnd = leafFirst + leafCount;
+        for (int i = leafFirst; i < leafEnd; i++) {
+            const float4 a0 = sc.tris48[3 * i], a1 = sc.tris48[3 * i + 1], a2 = sc.tris48[3 * i + 2];
+            tests++;
+            // intersectTriangle, geometry.glsl:31-51 (e1, e2 pre-subtracted at upload: same fp32 values)
+            const f3 v0 = xyz(a0), e1 = xyz(a1), e2 = xyz(a2);
+            const f3 pvec = cross(dir, e2);
+            const float det = dot(e1, pvec);
+            if (det < 0.0f) continue;
+            const f3 tvec = origin - v0;
+            const float u = dot(tvec, pvec);
+            if (u < 0.0f || u > det) continue;
+            const f3 qvec = cross(tvec, e1);
+            const float v = dot(dir, qvec);
+            if (v < 0.0f || (u + v) > det) continue;
+            const float invDet = 1.0f / det;
+            const float t = dot(e2, qvec) * invDet;
+            if (t >= 0.0f && t < nearest) { // intersectTriangles, trace3.cs:177: strict <, lowest index wins ties
+                nearest = t;
+                hit.t = t;
+                hit.u = u * invDet;
+                hit.v = v * invDet;
+                hit.tridx = i;
+            }
+        }
+    }
+    c.lastIterations = iterations;
+    c.rays++;
+    c.visits += (unsigned)iterations;
+    c.tests += tests;
+    return ok;
+}
+
+__device__ __forceinline__ const RtTri128 *triPtr(const RtScene &sc, int i) {
+    return (unsigned)i < (unsigned)sc.numTris ? sc.tris128 + i : nullptr;
+}
+__device__ __forceinline__ RtMtl fetchMtl(const RtScene &sc, int i) {
+    if ((unsigned)i < (unsigned)sc.numMtls) return sc.mtls[i];
+    RtMtl z = {{0, 0, 0}, 0, {0, 0, 0}, 0}; // out-of-range buffer reads give 0 on the oracle
+    return z;
+}
+
+// intersectGeometry's epilogue (trace3.cs:259-276): attributes of the closest hit
+__device__ __forceinline__ void intersectGeometry(const RtScene &sc, PathCtx &c, f3 origin, f3 dir, f3 invdir,
+                                                  Surface &SI) {
+    Hit h;
+    traverse(sc, c, origin, dir, invdir, h);
+    SI.tridx = h.tridx;
+    SI.normal = F3(0, 0, 0);
+    SI.point = F3(0, 0, 0);
+    SI.matidx = 0;
+    const RtTri128 *tri = triPtr(sc, h.tridx);
+    if (tri) {
+        const float u = h.u, v = h.v, w = 1.0f - u - v;
+        SI.normal = normalize((ld3(tri->n0) * w + ld3(tri->n1) * u) + ld3(tri->n2) * v); // :195-203
+        SI.point = origin + dir * h.t;
+        SI.matidx = tri->mtlIndex;
+        c.shaded++;
+    }
+}
+
+__device__ __forceinline__ LightTri loadLight(const RtScene &sc, int li) {
+    LightTri t;
+    if ((unsigned)li < (unsigned)sc.numEmitters) {
+        const RtTri128 *e = sc.emitters + li;
+        t.v0 = ld3(e->v0); t.v1 = ld3(e->v1); t.v2 = ld3(e->v2);
+        t.n0 = ld3(e->n0); t.n1 = ld3(e->n1); t.n2 = ld3(e->n2);
+        t.mtlIndex = e->mtlIndex;
+    } else {
+        t.v0 = t.v1 = t.v2 = t.n0 = t.n1 = t.n2 = F3(0, 0, 0);
+        t.mtlIndex = 0;
+    }
+    return t;
+}
+
+__device__ __forceinline__ bool eq3(f3 a, const float *b) { return a.x == b[0] && a.y == b[1] && a.z == b[2]; }
+
+// The comparison inside visible(), trace3.cs:492-496: the closest hit is, by value, the light triangle.
+// triangles[-1] (a miss) reads zeros on the oracle.
+__device__ __forceinline__ bool sameTriangle(const RtScene &sc, int tridx, const LightTri &t) {
+    const RtTri128 *ti = triPtr(sc, tridx);
+    if (!ti) {
+        const float z[3] = {0, 0, 0};
+        return eq3(t.v0, z) && eq3(t.v1, z) && eq3(t.v2, z) && eq3(t.n0, z) && eq3(t.n1, z) && eq3(t.n2, z) &&
+               t.mtlIndex == 0;
+    }
+    return eq3(t.v0, ti->v0) && eq3(t.v1, ti->v1) && eq3(t.v2, ti->v2) && eq3(t.n0, ti->n0) && eq3(t.n1, ti->n1) &&
+           eq3(t.n2, ti->n2) && t.mtlIndex == ti->mtlIndex;
+}
+
+// visible(), trace3.cs:487-497
+__device__ __forceinline__ bool visible(const RtScene &sc, PathCtx &c, f3 origin, f3 wi, const LightTri &t) {
+    Hit h;
+    traverse(sc, c, origin, wi, rcp3(wi), h);
+    return sameTriangle(sc, h.tridx, t);
+}
+
+__device__ __forceinline__ float PowerHeuristic(int nf, float fpdf, int ng, float gpdf) { // trace3.cs:499-503
+    float f = nf * fpdf, g = ng * gpdf;
+    return (f * f) / (f * f + g * g);
+}
+
+// brdfSpecular / brdfDiffuse, trace3.cs:332-348, with the surface's material already fetched
+__device__ __forceinline__ f3 brdfSpecular(float Ns, f3 i, f3 o, f3 n) {
+    f3 r = reflect(-i, n);
+    if (dot(r, o) < 0.0f) return F3(0, 0, 0);
+    float s = powf(fmaxf(0.0f, dot(r, o)), Ns) * (Ns + 2.0f) * ONE_OVER_2PI_T3;
+    return F3(s, s, s);
+}
+__device__ __forceinline__ f3 brdfDiffuse(f3 Kd) { return Kd * ONE_OVER_PI_T3; }
+
+// EstimateDirect (trace3.cs:505-572) in two halves, so that the two visibility rays it casts can be
+// traced elsewhere (wavefront.hip) or in place (trace3_kernel.hip) with identical arithmetic:
+// everything that does not depend on visibility ...
+struct DirectTerms {
+    f3 wi1, f1;   // light sample: direction, brdf * cos
+    float w1, lp1; // MIS weight, light pdf
+    int cond1;     // dot(SI.normal, wi1) >= 0
+    f3 wi2, f2;   // BRDF sample
+    float w2, bp2; // MIS weight, brdf pdf
+    int cond2;     // light_pdf != 0
+};
+__device__ __forceinline__ void estimateDirectPrepare(PathCtx &c, f3 origin, f3 dir, f3 normal, const RtMtl &surf,
+                                                      int bounces, const LightTri &light, DirectTerms &T) {
+    float light_pdf, brdf_pdf;
+    const float spec_rand = randfloat(c, bounces);
+    float2 sr = randvec2(c, bounces);
+    T.wi1 = randomTriangleAreaDirection(origin, light, sr.x, sr.y, light_pdf);
+    const f3 Kd = ld3(surf.Kd);
+    const float Ns = surf.Ns;
+    const f3 nn = normalize(normal);
+    if (spec_rand < SPECULARITY) {
+        f3 r = reflect(dir, normal);
+        brdf_pdf = randomPhongWeightedHemispherePDF(r, Ns, T.wi1);
+        T.f1 = brdfSpecular(Ns, T.wi1, -dir, normal);
+        T.f1 = T.f1 * dot(nn, normalize(T.wi1));
+    } else {
+        brdf_pdf = randomCosineWeightedHemispherePDF(normal, T.wi1);
+        T.f1 = brdfDiffuse(Kd) * dot(nn, normalize(T.wi1));
+    }
+    T.cond1 = dot(normal, T.wi1) >= 0;
+    T.w1 = PowerHeuristic(1, light_pdf, 1, brdf_pdf);
+    T.lp1 = light_pdf;
+
+    sr = randvec2(c, bounces);
+    if (spec_rand < SPECULARITY) {
+        f3 r = reflect(dir, normal);
+        T.wi2 = randomPhongWeightedHemispherePoint(r, Ns, sr.x, sr.y, brdf_pdf);
+        T.f2 = brdfSpecular(Ns, T.wi2, -dir, normal) * dot(nn, normalize(T.wi2));
+    } else {
+        T.wi2 = randomCosineWeightedHemispherePoint(normal, sr.x, sr.y, brdf_pdf);
+        T.f2 = brdfDiffuse(Kd) * dot(nn, normalize(T.wi2));
+    }
+    light_pdf = randomTriangleAreaDirectionPDF(origin, light, T.wi2);
+    T.w2 = PowerHeuristic(1, brdf_pdf, 1, light_pdf);
+    T.bp2 = brdf_pdf;
+    T.cond2 = light_pdf != 0;
+}
+// ... and the part that does: Ld of trace3.cs:541,570 given the two visible() results.
+__device__ __forceinline__ f3 estimateDirectResolve(const f3 f1, float w1, float lp1, int cond1, const f3 f2, float w2,
+                                                    float bp2, int cond2, f3 Ke30, bool vis1, bool vis2) {
+    f3 Ld = F3(0, 0, 0);
+    f3 Li = Ke30;
+    if (vis1 && cond1) Li = Li * 1.0f;
+    else Li = Li * 0.0f;
+    Ld = Ld + ((f1 * Li) * w1) / lp1;
+    Li = Ke30;
+    if (vis2) Li = Li * 1.0f;
+    else Li = Li * 0.0f;
+    if (cond2) Ld = Ld + ((f2 * Li) * w2) / bp2;
+    return Ld;
+}
+
+// UniformSampleOneLight's light pick, trace3.cs:574-582 + randomEmitterSample, random.glsl:221-251
+__device__ __forceinline__ int pickLight(PathCtx &c, int bounces, int numEmitters, float &light_prob) {
+    const float light_rand = randfloat(c, bounces);
+    light_prob = 1.0f / (float)numEmitters;
+    int li = (int)(light_rand * (float)numEmitters);
+    return min(li, numEmitters - 1);
+}
+
+// The continuation of trace(), trace3.cs:654-684: new direction, beta update, Russian roulette.
+// Returns false when the path is terminated by the roulette.
+__device__ __forceinline__ bool continuePath(PathCtx &c, int bounces, f3 normal, const RtMtl &m, f3 dir, f3 &beta,
+                                             f3 &wi) {
+    const f3 sample_rand = randvec3(c, bounces);
+    float pdf;
+    wi = randomHemispherePoint(normal, sample_rand.x, sample_rand.y, pdf); // sampleOutDir, trace3.cs:584-607
+    const f3 f = brdfSpecular(m.Ns, wi, -dir, normal) * SPECULARITY +
+                 brdfDiffuse(ld3(m.Kd)) * (1.0f - SPECULARITY); // brdf(), trace3.cs:350-355
+    beta = beta * ((f * dot(normalize(normal), normalize(wi))) / pdf);
+    const float rr_rand = randfloat(c, bounces);
+    const float rrbetamax = fmaxf(beta.x, fmaxf(beta.y, beta.z));
+    if (bounces > 3) {
+        const float q = fmaxf(0.05f, 1 - rrbetamax);
+        if (rr_rand < q) return false;
+        beta = beta / (1.0f - q);
+    }
+    return true;
+}
+
+// wave-wide sum with DPP/permute reductions, one atomic per wave
+__device__ __forceinline__ void waveAdd(unsigned long long *dst, unsigned v) {
+    unsigned long long s = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, s);
+}
+
+
+} // namespace
+
+#endif

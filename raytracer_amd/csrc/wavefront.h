@@ -1,0 +1,46 @@
+// wavefront.h — launch-side description of the wavefront path tracer (wavefront.hip).
+#ifndef RT_WAVEFRONT_H
+#define RT_WAVEFRONT_H
+
+#include "rt_device.h"
+
+#define WF_MAX_BATCH 16
+
+struct WfSample { // per-sample uniforms of a batch (what differs between successive Tracer::trace calls)
+    float time, blendFactor, oob0, oob1, oob2;
+};
+
+struct WfParams {
+    float eye[3], ray00[3], ray01[3], ray10[3], ray11[3];
+    int maxBounces, numEmitters, maxFollows, flags, batch;
+    WfSample s[WF_MAX_BATCH];
+};
+
+struct WfBuffers {
+    // path state, indexed by path id (= slot given at the primary hit)
+    float4 *L_seed;     // L.xyz, bits(seed)
+    float4 *beta;       // beta.xyz after the bounce's update, bits(pathFlags)
+    float4 *betaOld;    // beta.xyz the bounce's direct light is weighted with, bits(light index)
+    float4 *f1w1;       // light-sample term f1.xyz, MIS weight
+    float4 *f2w2;       // BRDF-sample term f2.xyz, MIS weight
+    float4 *pdfs;       // lp1, bp2, bits(cond1 | cond2<<1), unused
+    uint2 *pixSample;   // pixel index, sample index
+    int4 *pathStats;    // rays, visits, tests (RT_FLAG_PIXEL_STATS)
+    // ray queue: slot = kind * capacity + queue position
+    float4 *rayO;       // origin.xyz, valid (1.0 / 0.0)
+    float4 *rayD;       // dir.xyz
+    int4 *rayHit;       // tridx, bits(t), bits(u), bits(v)
+    int2 *rayWork;      // visits, tests of that traversal
+    int *queue[2];      // path ids, ping-pong
+    int *counts;        // [0..31] queue sizes per stage, [32..63] work cursors per stage
+    float4 *radiance;   // [sample][pixel in tile] finished L
+    int capacity;
+    int tilePixels;
+};
+
+hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfParams &p, const WfBuffers &wf,
+                             const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream);
+// bytes of device memory per unit of capacity (one path slot) and per (sample, tile pixel)
+size_t rtWavefrontBytesPerPath();
+
+#endif

@@ -1,0 +1,363 @@
+// wavefront.hip — the trace path as a wavefront (stream) path tracer for gfx950.
+//
+// Same per-path arithmetic as trace3_kernel.hip (both are built from trace3_device.h, which follows
+// reference src/shaders/trace3.cs / geometry.glsl / random.glsl); what changes is the schedule.
+// The per-pixel kernel keeps a lane on one path for up to 16 sequential BVH walks, so a frame in
+// which few pixels see geometry is bounded by its slowest wave while most of the chip idles, and
+// lanes whose paths have ended idle inside their wave.  Here a frame (a batch of 1..16 samples) is a
+// short sequence of launches over compacted queues:
+//
+//   primary   one lane per (pixel, sample), 8x8 pixel tiles per wave: ray generation + closest hit;
+//             misses finish immediately (sky), hits are appended to the path queue
+//   for bounce b = 0 .. maxBounces:
+//     logic   one lane per queued path: resolve the two shadow rays of bounce b-1 (MIS direct light),
+//             shade the hit of bounce b (emission, G-buffer at b = 0), stop or emit THREE rays —
+//             light-sample shadow ray, BRDF-sample shadow ray, continuation ray — and re-queue
+//     extend  persistent waves pull 64 rays at a time from the ray queue (one atomic per wave) and
+//             walk the BVH; the three rays of a path are traced concurrently by different lanes
+//   blend     per pixel, the samples of the batch are folded into the accumulation image in order
+//
+// so the dependent chain per path is maxBounces+1 traversals instead of 3*maxBounces+1, every wave of
+// `extend` is full of live rays, and ended paths cost nothing.  Rays are queued by kind (all light
+// rays, then all BRDF rays, then all continuation rays), which keeps the lanes of a wave similar.
+// Path state lives in HBM as structure-of-arrays of 16-byte records (coalesced 16 B per lane).
+// Results are identical to the per-pixel kernel's for every pixel (same operations in the same order
+// per path); only the order in which paths are processed differs.
+#include "trace3_device.h"
+#include "wavefront.h"
+
+namespace {
+
+__device__ __forceinline__ int waveAppend(int *counter, bool want) {
+    // wave-aggregated append: one atomic per wave, returns this lane's slot (or -1)
+    const unsigned long long mask = __ballot(want);
+    if (!mask) return -1;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(mask));
+    base = __shfl(base, leader, 64);
+    return want ? base + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
+}
+
+__device__ __forceinline__ PathCtx makeCtx(const WfParams &p, int x, int y, int sample, int seed) {
+    PathCtx c;
+    c.px = x;
+    c.py = y;
+    c.time = p.s[sample].time;
+    c.seed = seed;
+    c.oob0 = p.s[sample].oob0;
+    c.oob1 = p.s[sample].oob1;
+    c.oob2 = p.s[sample].oob2;
+    c.maxFollows = p.maxFollows;
+    c.rays = c.visits = c.tests = c.shaded = 0;
+    c.lastIterations = 0;
+    return c;
+}
+
+__device__ __forceinline__ void flushCounters(const WfParams &p, RtCountersDev *counters, const PathCtx &c,
+                                              unsigned paths) {
+    if (p.flags & RT_FLAG_NO_COUNTERS) return;
+    waveAdd(&counters->rays, c.rays);
+    waveAdd(&counters->node_visits, c.visits);
+    waveAdd(&counters->tri_tests, c.tests);
+    waveAdd(&counters->shaded_hits, c.shaded);
+    waveAdd(&counters->paths, paths);
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------ primary
+__global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
+                                                            rt_rect tile, int tilesX, int tilesY, int xcdRemap,
+                                                            RtCountersDev *counters) {
+    const int tilesPerSample = tilesX * tilesY;
+    const int nblocks = gridDim.x;
+    const int b = blockIdx.x;
+    const int perXcd = nblocks / 8;
+    const int t = xcdRemap ? (b % 8) * perXcd + b / 8 : b;
+    const bool live = t < tilesPerSample * p.batch;
+    const int sample = live ? t / tilesPerSample : 0;
+    const int ts = t - sample * tilesPerSample;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx = (lane & 7) + 8 * (wave & 1), ly = (lane >> 3) + 8 * (wave >> 1);
+    const int x = tile.x0 + (ts % tilesX) * 16 + lx, y = tile.y0 + (ts / tilesX) * 16 + ly;
+    const bool active = live && x < tile.x1 && y < tile.y1;
+
+    PathCtx c = makeCtx(p, x, y, sample, 0);
+    bool queued = false;
+    Hit h;
+    h.tridx = -1;
+    h.t = h.u = h.v = 0.0f;
+    f3 dir = F3(0, 0, 0);
+    const int W = img.width, H = img.height;
+    if (active) {
+        // trace3.cs:805-807
+        const float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
+        dir = normalize(mix(mix(ld3(p.ray00), ld3(p.ray01), pyf), mix(ld3(p.ray10), ld3(p.ray11), pyf), pxf));
+        traverse(sc, c, ld3(p.eye), dir, rcp3(dir), h);
+        const size_t pix = (size_t)y * W + x;
+        if (p.flags & RT_FLAG_AUX) {
+            img.tridx[pix] = h.tridx;
+            img.visits[pix] = c.lastIterations;
+        }
+        if (h.tridx == -1) {
+            // trace(): L += beta * SKY_COLOR; write(vec3(0), vec3(0)); break   (trace3.cs:639-647)
+            const f3 L = F3(0, 0, 0) + F3(1, 1, 1) * F3(0.89f, 0.96f, 1.00f);
+            img.normal[pix] = 0u;
+            img.pos[pix] = make_uint2(pack_half2_rtz(0.0f, 0.0f), pack_half2_rtz(0.0f, 1.0f));
+            const int tp = (y - tile.y0) * (tile.x1 - tile.x0) + (x - tile.x0);
+            wf.radiance[(size_t)sample * wf.tilePixels + tp] = make_float4(L.x, L.y, L.z, 1.0f);
+            // the statistics image shows the last sample of the batch, as successive dispatches would leave it
+            if ((p.flags & RT_FLAG_PIXEL_STATS) && sample == p.batch - 1)
+                img.stats[pix] = make_int4((int)c.rays, (int)c.visits, (int)c.tests, 0);
+        } else {
+            queued = true;
+        }
+    }
+    const int slot = waveAppend(&wf.counts[0], queued);
+    if (queued) {
+        // path id = queue position at stage 0; the primary ray sits in the continuation-ray segment
+        wf.queue[0][slot] = slot;
+        wf.pixSample[slot] = make_uint2((unsigned)(y * W + x), (unsigned)sample);
+        wf.L_seed[slot] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
+        wf.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
+        const size_t r = (size_t)2 * wf.capacity + slot;
+        wf.rayO[r] = make_float4(p.eye[0], p.eye[1], p.eye[2], 1.0f);
+        wf.rayD[r] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+        wf.rayHit[r] = make_int4(h.tridx, __float_as_int(h.t), __float_as_int(h.u), __float_as_int(h.v));
+        if (p.flags & RT_FLAG_PIXEL_STATS) wf.pathStats[slot] = make_int4((int)c.rays, (int)c.visits, (int)c.tests, 0);
+    }
+    flushCounters(p, counters, c, active ? 1u : 0u);
+}
+
+// ------------------------------------------------------------------------------------------ logic
+#define WF_FLAG_PENDING 1 // the path has shadow rays of the previous bounce to resolve
+#define WF_FLAG_ENDED 2   // terminated by the roulette: resolve, then finish (no continuation ray was cast)
+
+__global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
+                                                          rt_rect tile, int bounce, RtCountersDev *counters) {
+    const int n = min(wf.counts[bounce], wf.capacity);
+    const int *qin = wf.queue[bounce & 1];
+    int *qout = wf.queue[(bounce + 1) & 1];
+    const size_t cap = (size_t)wf.capacity;
+    const int W = img.width;
+    const int rounds = (n + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
+    unsigned shaded = 0;
+    for (int round = 0; round < rounds; ++round) {
+        const int i = (round * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        const bool have = i < n;
+        bool requeue = false;
+        int pid = 0;
+        // values the re-queue step needs
+        float4 rO[3], rD[3];
+        if (have) {
+            pid = qin[i];
+            const uint2 ps = wf.pixSample[pid];
+            const int pix = (int)ps.x, sample = (int)ps.y;
+            const int x = pix % W, y = pix / W;
+            float4 Ls = wf.L_seed[pid];
+            float4 bt = wf.beta[pid];
+            f3 L = F3(Ls.x, Ls.y, Ls.z), beta = F3(bt.x, bt.y, bt.z);
+            int flags = __float_as_int(bt.w);
+            PathCtx c = makeCtx(p, x, y, sample, __float_as_int(Ls.w));
+            int4 stats = make_int4(0, 0, 0, 0);
+            const bool wantStats = (p.flags & RT_FLAG_PIXEL_STATS) != 0;
+            if (wantStats) stats = wf.pathStats[pid];
+
+            if (flags & WF_FLAG_PENDING) {
+                // finish EstimateDirect of the previous bounce (trace3.cs:533-571) and L += beta * Ld (:652)
+                const float4 bo = wf.betaOld[pid], a1 = wf.f1w1[pid], a2 = wf.f2w2[pid], pd = wf.pdfs[pid];
+                const int li = __float_as_int(bo.w);
+                const LightTri light = loadLight(sc, li);
+                const int conds = __float_as_int(pd.z);
+                const bool vis1 = sameTriangle(sc, wf.rayHit[i].x, light);
+                const bool vis2 = sameTriangle(sc, wf.rayHit[cap + i].x, light);
+                const f3 Ke30 = ld3(fetchMtl(sc, light.mtlIndex).Ke) * 30.0f;
+                const float light_prob = 1.0f / (float)p.numEmitters;
+                const f3 Ld = estimateDirectResolve(F3(a1.x, a1.y, a1.z), a1.w, pd.x, conds & 1, F3(a2.x, a2.y, a2.z),
+                                                    a2.w, pd.y, (conds >> 1) & 1, Ke30, vis1, vis2) / light_prob;
+                L = L + F3(bo.x, bo.y, bo.z) * Ld;
+                if (wantStats) {
+                    const int2 w0 = wf.rayWork[i], w1 = wf.rayWork[cap + i];
+                    stats.x += 2;
+                    stats.y += w0.x + w1.x;
+                    stats.z += w0.y + w1.y;
+                }
+            }
+
+            bool finished = (flags & WF_FLAG_ENDED) != 0;
+            if (!finished) {
+                // the hit of this bounce: result of the continuation (or primary) ray
+                const size_t r = 2 * cap + i;
+                const int4 hr = wf.rayHit[r];
+                const float4 ro = wf.rayO[r], rd = wf.rayD[r];
+                const f3 origin = F3(ro.x, ro.y, ro.z), dir = F3(rd.x, rd.y, rd.z);
+                if (wantStats && bounce > 0) {
+                    const int2 w2 = wf.rayWork[r];
+                    stats.x += 1;
+                    stats.y += w2.x;
+                    stats.z += w2.y;
+                }
+                // intersectGeometry's epilogue (trace3.cs:259-276)
+                Surface SI;
+                SI.tridx = hr.x;
+                SI.normal = F3(0, 0, 0);
+                SI.point = F3(0, 0, 0);
+                SI.matidx = 0;
+                const RtTri128 *tri = triPtr(sc, hr.x);
+                if (tri) {
+                    const float u = __int_as_float(hr.z), v = __int_as_float(hr.w), w = 1.0f - u - v;
+                    SI.normal = normalize((ld3(tri->n0) * w + ld3(tri->n1) * u) + ld3(tri->n2) * v);
+                    SI.point = origin + dir * __int_as_float(hr.y);
+                    SI.matidx = tri->mtlIndex;
+                    shaded++;
+                }
+                const bool found = SI.tridx != -1;
+                const RtMtl m = fetchMtl(sc, SI.matidx);
+                if (found) {
+                    if (m.emitter) L = L + (beta * ld3(m.Ke)) * 30.0f;
+                } else {
+                    L = L + beta * F3(0.89f, 0.96f, 1.00f);
+                }
+                if (bounce == 0) { // write(), trace3.cs:357-361 (a miss at bounce 0 never reaches this kernel)
+                    img.normal[pix] = snorm8(SI.normal.x) | (snorm8(SI.normal.y) << 8) | (snorm8(SI.normal.z) << 16);
+                    img.pos[pix] = make_uint2(pack_half2_rtz(SI.point.x, SI.point.y), pack_half2_rtz(SI.point.z, 1.0f));
+                }
+                if (!found || bounce >= p.maxBounces) {
+                    finished = true;
+                } else {
+                    const f3 o2 = SI.point + SI.normal * EPSILON_F;
+                    float light_prob;
+                    const int li = pickLight(c, bounce, p.numEmitters, light_prob);
+                    const LightTri light = loadLight(sc, li);
+                    DirectTerms T;
+                    estimateDirectPrepare(c, o2, dir, SI.normal, m, bounce, light, T);
+                    const f3 betaOld = beta;
+                    f3 wi;
+                    const bool alive = continuePath(c, bounce, SI.normal, m, dir, beta, wi);
+                    wf.betaOld[pid] = make_float4(betaOld.x, betaOld.y, betaOld.z, __int_as_float(li));
+                    wf.f1w1[pid] = make_float4(T.f1.x, T.f1.y, T.f1.z, T.w1);
+                    wf.f2w2[pid] = make_float4(T.f2.x, T.f2.y, T.f2.z, T.w2);
+                    wf.pdfs[pid] = make_float4(T.lp1, T.bp2, __int_as_float(T.cond1 | (T.cond2 << 1)), 0.0f);
+                    flags = WF_FLAG_PENDING | (alive ? 0 : WF_FLAG_ENDED);
+                    rO[0] = rO[1] = make_float4(o2.x, o2.y, o2.z, 1.0f);
+                    rO[2] = make_float4(o2.x, o2.y, o2.z, alive ? 1.0f : 0.0f);
+                    rD[0] = make_float4(T.wi1.x, T.wi1.y, T.wi1.z, 0.0f);
+                    rD[1] = make_float4(T.wi2.x, T.wi2.y, T.wi2.z, 0.0f);
+                    rD[2] = make_float4(wi.x, wi.y, wi.z, 0.0f);
+                    requeue = true;
+                }
+            }
+            if (requeue) {
+                wf.L_seed[pid] = make_float4(L.x, L.y, L.z, __int_as_float(c.seed));
+                wf.beta[pid] = make_float4(beta.x, beta.y, beta.z, __int_as_float(flags));
+                if (wantStats) wf.pathStats[pid] = stats;
+            } else {
+                // the path is complete: hand its radiance to the blend step
+                const int tp = (y - tile.y0) * (tile.x1 - tile.x0) + (x - tile.x0);
+                wf.radiance[(size_t)sample * wf.tilePixels + tp] = make_float4(L.x, L.y, L.z, 1.0f);
+                if (wantStats && sample == p.batch - 1) img.stats[pix] = stats;
+            }
+        }
+        const int slot = waveAppend(&wf.counts[bounce + 1], requeue);
+        if (requeue) {
+            qout[slot] = pid;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                wf.rayO[k * cap + slot] = rO[k];
+                wf.rayD[k * cap + slot] = rD[k];
+            }
+        }
+    }
+    if (!(p.flags & RT_FLAG_NO_COUNTERS)) waveAdd(&counters->shaded_hits, shaded);
+}
+
+// ------------------------------------------------------------------------------------------ extend
+// Persistent waves: each wave takes 64 consecutive rays of the stage's queue with one atomic, walks
+// them, stores the hits, and comes back for more until the queue is drained.
+__global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams p, WfBuffers wf, int stage,
+                                                           RtCountersDev *counters) {
+    const int n = min(wf.counts[stage], wf.capacity);
+    const int total = 3 * n;
+    const size_t cap = (size_t)wf.capacity;
+    const int lane = threadIdx.x & 63;
+    PathCtx c = makeCtx(p, 0, 0, 0, 0);
+    for (;;) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&wf.counts[32 + stage], 64);
+        base = __shfl(base, 0, 64);
+        if (base >= total) break;
+        const int w = base + lane;
+        if (w < total) {
+            const int kind = w / n, j = w - kind * n;
+            const size_t r = kind * cap + j;
+            const float4 ro = wf.rayO[r];
+            if (ro.w != 0.0f) {
+                const float4 rd = wf.rayD[r];
+                const f3 dir = F3(rd.x, rd.y, rd.z);
+                Hit h;
+                const unsigned v0 = c.visits, t0 = c.tests;
+                traverse(sc, c, F3(ro.x, ro.y, ro.z), dir, rcp3(dir), h);
+                wf.rayHit[r] = make_int4(h.tridx, __float_as_int(h.t), __float_as_int(h.u), __float_as_int(h.v));
+                if (p.flags & RT_FLAG_PIXEL_STATS) wf.rayWork[r] = make_int2((int)(c.visits - v0), (int)(c.tests - t0));
+            } else if (p.flags & RT_FLAG_PIXEL_STATS) {
+                wf.rayWork[r] = make_int2(0, 0);
+            }
+        }
+    }
+    c.shaded = 0;
+    flushCounters(p, counters, c, 0u);
+}
+
+// ------------------------------------------------------------------------------------------ blend
+// main()'s accumulation (trace3.cs:808-817), once per sample of the batch, in sample order.
+__global__ __launch_bounds__(256) void rt_wf_blend_kernel(RtImages img, WfParams p, WfBuffers wf, rt_rect tile) {
+    const int tw = tile.x1 - tile.x0;
+    const int n = wf.tilePixels;
+    for (int tp = blockIdx.x * 256 + threadIdx.x; tp < n; tp += gridDim.x * 256) {
+        const int x = tile.x0 + tp % tw, y = tile.y0 + tp / tw;
+        const size_t pix = (size_t)y * img.width + x;
+        float4 cur = make_float4(0, 0, 0, 0);
+        bool loaded = false;
+        for (int k = 0; k < p.batch; ++k) {
+            const float4 Lk = wf.radiance[(size_t)k * n + tp];
+            f3 old = F3(0, 0, 0);
+            if (p.s[k].blendFactor > 0.0f) {
+                if (!loaded && k == 0) cur = img.color[pix];
+                old = F3(cur.x, cur.y, cur.z);
+            }
+            loaded = true;
+            const f3 fin = mix(F3(Lk.x, Lk.y, Lk.z), old, p.s[k].blendFactor);
+            cur = make_float4(fin.x, fin.y, fin.z, 1.0f);
+        }
+        img.color[pix] = cur;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+size_t rtWavefrontBytesPerPath() { return 6 * 16 + 8 + 16 + 3 * (16 + 16 + 16 + 8) + 2 * 4; }
+
+hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfParams &p, const WfBuffers &wf,
+                             const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream) {
+    const int tw = tile.x1 - tile.x0, th = tile.y1 - tile.y0;
+    if (tw <= 0 || th <= 0 || p.batch <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(wf.counts, 0, 64 * sizeof(int), stream);
+    if (e != hipSuccess) return e;
+    const int tilesX = (tw + 15) / 16, tilesY = (th + 15) / 16;
+    const int ntiles = tilesX * tilesY * p.batch;
+    const int nblocks = ((ntiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(rt_wf_primary_kernel, dim3(nblocks), dim3(256), 0, stream, sc, img, p, wf, tile, tilesX, tilesY,
+                       xcdRemap, counters);
+    // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
+    const int logicBlocks = 256 * 4, extendBlocks = 256 * 6;
+    for (int b = 0; b <= p.maxBounces; ++b) {
+        hipLaunchKernelGGL(rt_wf_logic_kernel, dim3(logicBlocks), dim3(256), 0, stream, sc, img, p, wf, tile, b, counters);
+        if (b < p.maxBounces)
+            hipLaunchKernelGGL(rt_wf_extend_kernel, dim3(extendBlocks), dim3(256), 0, stream, sc, p, wf, b + 1, counters);
+    }
+    int blendBlocks = (tw * th + 255) / 256;
+    if (blendBlocks > 4096) blendBlocks = 4096;
+    hipLaunchKernelGGL(rt_wf_blend_kernel, dim3(blendBlocks), dim3(256), 0, stream, img, p, wf, tile);
+    return hipGetLastError();
+}

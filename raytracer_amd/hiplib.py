@@ -12,7 +12,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "librt_hip.so")
 (IMAGE_COLOR, IMAGE_NORMAL, IMAGE_POSITION, IMAGE_FILTERED, IMAGE_TRIDX, IMAGE_VISITS, IMAGE_STATS,
  IMAGE_LDR) = range(8)
 KERNEL_TRACE3, KERNEL_TRACE3_RL, KERNEL_TRACE, KERNEL_TRACE1, KERNEL_TRACE2 = range(5)
-FLAG_AUX, FLAG_PIXEL_STATS, FLAG_NO_COUNTERS = 1, 2, 4
+FLAG_AUX, FLAG_PIXEL_STATS, FLAG_NO_COUNTERS, FLAG_PER_PIXEL_KERNEL = 1, 2, 4, 8
+MAX_BATCH = 16
 TABLE_SOBOL, TABLE_SCRAMBLE, TABLE_RANKING, TABLE_LTC1, TABLE_LTC2 = range(5)
 
 _IMAGE_DTYPES = {IMAGE_COLOR: (np.float32, 4), IMAGE_NORMAL: (np.int8, 4), IMAGE_POSITION: (np.float16, 4),
@@ -50,7 +51,7 @@ class Timings(ctypes.Structure):
 
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_upload", "rt_set_table", "rt_resize",
-           "rt_clear", "rt_trace", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
+           "rt_clear", "rt_trace", "rt_trace_batch", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
            "rt_readback_rect_device", "rt_write_rect_device", "rt_write_image", "rt_image_pixel_bytes",
            "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
            "rt_work_group_size", "rt_version"]
@@ -78,6 +79,7 @@ def lib():
         L.rt_resize.argtypes = [vp, i32, i32]
         L.rt_clear.argtypes = [vp]
         L.rt_trace.argtypes = [vp, ctypes.POINTER(TraceParams), rp]
+        L.rt_trace_batch.argtypes = [vp, ctypes.POINTER(TraceParams), i32, rp]
         L.rt_filter.argtypes = [vp, i32, fl, fl, fl, rp]
         L.rt_filter_halo.argtypes = [i32]
         L.rt_tonemap.argtypes = [vp, i32, fl, rp]
@@ -177,15 +179,27 @@ class Context:
     def trace(self, params, rect=None):
         self._check(lib().rt_trace(self._h, ctypes.byref(params), self._rect(rect)), "rt_trace")
 
+    def trace_batch(self, params_list, rect=None):
+        arr = (TraceParams * len(params_list))(*params_list)
+        self._check(lib().rt_trace_batch(self._h, arr, len(params_list), self._rect(rect)), "rt_trace_batch")
+
     def trace_samples(self, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.0625, max_bounces=5, flags=0,
-                      rect=None, num_emitters=None, oob="llvmpipe", max_follows=1000):
-        """spp dispatches with time_k = time0 + dtime*k and blendFactor_k = k/(k+1)."""
+                      rect=None, num_emitters=None, oob="llvmpipe", max_follows=1000, batch=MAX_BATCH):
+        """spp dispatches with time_k = time0 + dtime*k and blendFactor_k = k/(k+1), issued in groups of
+        up to `batch` concurrent samples (rt_trace_batch; batch=1 issues one rt_trace per sample)."""
         ne = self.num_emitters if num_emitters is None else num_emitters
+        plist = []
         for k in range(spp):
             frame = frame0 + k
             t = np.float32(time0) + np.float32(dtime) * np.float32(frame)
             bf = np.float32(frame) / (np.float32(frame) + np.float32(1.0))
-            self.trace(make_params(rays, eye, t, bf, max_bounces, ne, flags, max_follows=max_follows, oob=oob), rect)
+            plist.append(make_params(rays, eye, t, bf, max_bounces, ne, flags, max_follows=max_follows, oob=oob))
+        if batch <= 1:
+            for p in plist:
+                self.trace(p, rect)
+        else:
+            for i in range(0, spp, batch):
+                self.trace_batch(plist[i:i + batch], rect)
 
     def filter(self, iterations, c_phi0=3.3, n_phi0=1e-2, p_phi0=5.5, rect=None):
         self._check(lib().rt_filter(self._h, iterations, c_phi0, n_phi0, p_phi0, self._rect(rect)), "rt_filter")

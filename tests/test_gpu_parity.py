@@ -95,6 +95,34 @@ def test_trace_against_oracle(ctx, scene, w, h, spp, mb):
     assert abs(int(got["stats"][..., 0].sum()) - int(ref["stats"][..., 0].sum())) <= 0.002 * ref["stats"][..., 0].sum()
 
 
+@pytest.mark.parametrize("scene,w,h,spp,mb", [("room", 120, 90, 3, 5), ("scene", 400, 225, 4, 5), ("teapot", 96, 64, 2, 0)])
+def test_schedules_are_bit_identical(ctx, scene, w, h, spp, mb):
+    """Wavefront pipeline with concurrent samples, wavefront one sample at a time, and the
+    one-lane-per-path kernel: every image and every counter must be identical."""
+    wl = workloads.Workload(scene, w, h)
+    results = []
+    for kw in (dict(), dict(batch=1), dict(batch=1, flags=hiplib.FLAG_AUX | hiplib.FLAG_PIXEL_STATS | hiplib.FLAG_PER_PIXEL_KERNEL)):
+        got = render(ctx, wl, spp, mb, **kw)
+        c = ctx.counters()
+        results.append((got, (c.rays, c.node_visits, c.tri_tests, c.shaded_hits, c.paths)))
+    for got, cnt in results[1:]:
+        assert cnt == results[0][1]
+        for k in got:
+            assert np.array_equal(got[k].view(np.uint8), results[0][0][k].view(np.uint8)), k
+
+
+def test_batch_argument_checks(ctx):
+    wl = workloads.Workload("room", 32, 32)
+    ctx.upload_scene(wl.buffers)
+    ctx.resize(32, 32)
+    a = hiplib.make_params(wl.rays, wl.eye, 1.25, 0.0, 5, 2)
+    b = hiplib.make_params(wl.rays, wl.eye, 1.3125, 0.5, 4, 2)   # maxBounces differs: not allowed in one batch
+    with pytest.raises(hiplib.RtError):
+        ctx.trace_batch([a, b])
+    with pytest.raises(hiplib.RtError):
+        ctx.trace_batch([a] * 17)
+
+
 def test_full_size_radiance_and_counters_against_oracle(ctx):
     """The metric configuration itself (scene.obj 1920x1080 4 spp, 5 bounces) against the oracle."""
     wl = workloads.Workload("scene", 1920, 1080)
