@@ -115,11 +115,23 @@ typedef struct rt_counters {
     uint64_t paths;       /* pixel-samples                                                              */
 } rt_counters;
 
-/* Accumulated device time, measured with HIP events on the context's stream when profiling is on. */
+/* Accumulated device time per kernel family, measured with HIP events on the context's stream while
+ * profiling is on (rt_profile).  RT_TIME_TRACE spans a whole rt_trace / rt_trace_batch call; the
+ * RT_TIME_WF_* entries split it into the kernels of the wavefront pipeline. */
+enum rt_time_kind {
+    RT_TIME_TRACE = 0,      /* one span per rt_trace / rt_trace_batch call                    */
+    RT_TIME_FILTER = 1,     /* one span per à-trous pass                                      */
+    RT_TIME_TONEMAP = 2,
+    RT_TIME_WF_PRIMARY = 3, /* ray generation + primary closest hit                           */
+    RT_TIME_WF_LOGIC = 4,   /* shading / light sampling / queueing, one launch per bounce     */
+    RT_TIME_WF_EXTEND = 5,  /* persistent BVH traversal of the ray queue, one launch per bounce */
+    RT_TIME_WF_BLEND = 6,
+    RT_TIME_PER_PIXEL = 7,  /* the one-lane-per-path kernel (RT_FLAG_PER_PIXEL_KERNEL)         */
+    RT_TIME_KINDS = 8
+};
 typedef struct rt_timings {
-    double trace_ms;  uint64_t trace_launches;
-    double filter_ms; uint64_t filter_launches; /* one launch per à-trous pass */
-    double tonemap_ms; uint64_t tonemap_launches;
+    double ms[8];
+    uint64_t launches[8];
 } rt_timings;
 
 enum rt_image {

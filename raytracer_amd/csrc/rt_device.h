@@ -62,9 +62,16 @@ struct RtImages {
     int width, height;
 };
 
-struct RtCountersDev {
+// Global counters are sharded: every wave adds to the shard its block/wave number selects, each shard
+// on a 128-byte line of its own, and rt_counters_read sums the shards.  One word shared by every wave
+// of a launch serialises at the memory side (measured: ~88 atomics/us on one address, which cost the
+// first version of the trace kernels milliseconds per launch).
+#define RT_COUNTER_SHARDS 256
+struct __attribute__((aligned(128))) RtCountersDev {
     unsigned long long rays, node_visits, tri_tests, shaded_hits, paths;
+    unsigned long long pad[11];
 };
+static_assert(sizeof(RtCountersDev) == 128, "one shard per 128-byte line");
 
 // ---------------------------------------------------------------------------------------
 struct f3 {

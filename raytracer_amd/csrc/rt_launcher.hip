@@ -5,7 +5,9 @@
 // two RGBA16F ping-pong images of the filter, auxiliary ID / statistics images and counters.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -16,6 +18,9 @@
 
 hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace_params &p, const rt_rect &tile,
                           int xcdRemap, RtCountersDev *counters, hipStream_t stream);
+// Called by the wavefront launcher between its kernels when profiling is on.
+struct rt_ctx;
+void rtMarkKernel(void *ctxOpaque, int kind, bool begin);
 hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const uint32_t *normal, const uint2 *pos,
                           uint2 *out, int W, int H, const rt_rect &rect, float c_phi, float n_phi, float p_phi,
                           int step, hipStream_t stream);
@@ -30,7 +35,7 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
-enum TimeKind { TK_TRACE = 0, TK_FILTER = 1, TK_TONEMAP = 2 };
+enum TimeKind { TK_TRACE = RT_TIME_TRACE, TK_FILTER = RT_TIME_FILTER, TK_TONEMAP = RT_TIME_TONEMAP };
 
 struct TimedSpan {
     hipEvent_t start, stop;
@@ -56,15 +61,16 @@ struct rt_ctx {
     int filteredIndex = -1; // which of filt[] holds the result of the last rt_filter
 
     // wavefront path tracer state (wavefront.h), grown on demand
-    DevBuf wfState[8], wfRay[4], wfQueue[2], wfCounts, wfRadiance;
+    DevBuf wfState[8], wfRay[6], wfQueue[2], wfCounts, wfRadiance;
     size_t wfCapacity = 0, wfRadianceSlots = 0;
+    int tuneRefillLanes = 64, tuneExtendBlocks = 4; // development knobs: RT_WF_REFILL, RT_WF_BLOCKS
 
     DevBuf counters;
     bool profile = false;
     std::vector<TimedSpan> spans;
     std::vector<hipEvent_t> eventPool;
-    double accMs[3] = {0, 0, 0};
-    uint64_t accN[3] = {0, 0, 0};
+    double accMs[RT_TIME_KINDS] = {};
+    uint64_t accN[RT_TIME_KINDS] = {};
 };
 
 namespace {
@@ -166,6 +172,25 @@ struct SpanGuard { // records start on construction, stop on end()
     }
 };
 
+} // namespace
+
+void rtMarkKernel(void *opaque, int kind, bool begin) {
+    rt_ctx *c = static_cast<rt_ctx *>(opaque);
+    if (!c || !c->profile) return;
+    static thread_local TimedSpan cur;
+    if (begin) {
+        cur.kind = kind;
+        cur.start = takeEvent(c);
+        cur.stop = takeEvent(c);
+        (void)hipEventRecord(cur.start, c->stream);
+    } else {
+        (void)hipEventRecord(cur.stop, c->stream);
+        c->spans.push_back(cur);
+    }
+}
+
+namespace {
+
 bool rectOk(const rt_ctx *c, const rt_rect &r) {
     return r.x0 >= 0 && r.y0 >= 0 && r.x1 <= c->width && r.y1 <= c->height && r.x0 <= r.x1 && r.y0 <= r.y1;
 }
@@ -227,8 +252,10 @@ int rt_create(int device_id, rt_ctx **out) {
         return RT_ENODEV;
     }
     c->stream = c->ownStream;
-    if (ensure(c, c->counters, sizeof(RtCountersDev)) != RT_OK ||
-        hipMemsetAsync(c->counters.p, 0, sizeof(RtCountersDev), c->stream) != hipSuccess) {
+    if (const char *e = std::getenv("RT_WF_REFILL")) c->tuneRefillLanes = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("RT_WF_BLOCKS")) c->tuneExtendBlocks = std::max(1, std::min(8, std::atoi(e)));
+    if (ensure(c, c->counters, sizeof(RtCountersDev) * RT_COUNTER_SHARDS) != RT_OK ||
+        hipMemsetAsync(c->counters.p, 0, sizeof(RtCountersDev) * RT_COUNTER_SHARDS, c->stream) != hipSuccess) {
         (void)hipStreamDestroy(c->ownStream);
         delete c;
         return RT_ENOMEM;
@@ -418,9 +445,9 @@ int ensureWavefront(rt_ctx *c, size_t capacity, size_t radianceSlots, WfBuffers 
             if ((r = ensure(c, c->wfState[k], cap * 16))) return r;
         if ((r = ensure(c, c->wfState[6], cap * 8))) return r;  // pixSample
         if ((r = ensure(c, c->wfState[7], cap * 16))) return r; // pathStats
-        if ((r = ensure(c, c->wfRay[0], 3 * cap * 16)) || (r = ensure(c, c->wfRay[1], 3 * cap * 16)) ||
-            (r = ensure(c, c->wfRay[2], 3 * cap * 16)) || (r = ensure(c, c->wfRay[3], 3 * cap * 8)))
-            return r;
+        for (int k = 0; k < 5; ++k)
+            if ((r = ensure(c, c->wfRay[k], 3 * cap * 16))) return r;
+        if ((r = ensure(c, c->wfRay[5], 3 * cap * 8))) return r;
         if ((r = ensure(c, c->wfQueue[0], cap * 4)) || (r = ensure(c, c->wfQueue[1], cap * 4))) return r;
         c->wfCapacity = cap;
     }
@@ -437,10 +464,12 @@ int ensureWavefront(rt_ctx *c, size_t capacity, size_t radianceSlots, WfBuffers 
     wf.pdfs = (float4 *)c->wfState[5].p;
     wf.pixSample = (uint2 *)c->wfState[6].p;
     wf.pathStats = (int4 *)c->wfState[7].p;
-    wf.rayO = (float4 *)c->wfRay[0].p;
-    wf.rayD = (float4 *)c->wfRay[1].p;
-    wf.rayHit = (int4 *)c->wfRay[2].p;
-    wf.rayWork = (int2 *)c->wfRay[3].p;
+    wf.rayO[0] = (float4 *)c->wfRay[0].p;
+    wf.rayO[1] = (float4 *)c->wfRay[1].p;
+    wf.rayD[0] = (float4 *)c->wfRay[2].p;
+    wf.rayD[1] = (float4 *)c->wfRay[3].p;
+    wf.rayHit = (int4 *)c->wfRay[4].p;
+    wf.rayWork = (int2 *)c->wfRay[5].p;
     wf.queue[0] = (int *)c->wfQueue[0].p;
     wf.queue[1] = (int *)c->wfQueue[1].p;
     wf.counts = (int *)c->wfCounts.p;
@@ -493,8 +522,9 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
                               tilePixels * (size_t)n > ((size_t)1 << 30);
         if (perPixel) {
             for (int k = 0; k < n; ++k) {
-                SpanGuard span(c, TK_TRACE);
+                SpanGuard span(c, TK_TRACE), span2(c, RT_TIME_PER_PIXEL);
                 hipError_t e = rtLaunchTrace3(sc, img, params[k], r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream);
+                span2.end();
                 span.end();
                 if (e != hipSuccess) return hipFail(c, e, "trace3 launch");
             }
@@ -515,6 +545,8 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         wp.maxFollows = p->maxFollows > 0 ? p->maxFollows : 1000;
         wp.flags = p->flags;
         wp.batch = n;
+        wp.refillLanes = c->tuneRefillLanes;
+        wp.extendBlocksPerCU = c->tuneExtendBlocks;
         for (int k = 0; k < n; ++k) {
             wp.s[k].time = params[k].time;
             wp.s[k].blendFactor = params[k].blendFactor;
@@ -523,7 +555,8 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             wp.s[k].oob2 = params[k].oobSeeds[2];
         }
         SpanGuard span(c, TK_TRACE);
-        hipError_t e = rtLaunchWavefront(sc, img, wp, wf, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream);
+        hipError_t e = rtLaunchWavefront(sc, img, wp, wf, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream,
+                                         c->profile ? c : nullptr);
         span.end();
         if (e != hipSuccess) return hipFail(c, e, "wavefront launch");
         return RT_OK;
@@ -662,14 +695,18 @@ int rt_counters_read(rt_ctx *c, rt_counters *out) {
     if (!c || !out) return RT_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
-    RtCountersDev h;
-    HIP_TRY(c, hipMemcpyAsync(&h, c->counters.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    std::vector<RtCountersDev> h(RT_COUNTER_SHARDS);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->counters.p, sizeof(RtCountersDev) * RT_COUNTER_SHARDS, hipMemcpyDeviceToHost,
+                              c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    out->rays = h.rays;
-    out->node_visits = h.node_visits;
-    out->tri_tests = h.tri_tests;
-    out->shaded_hits = h.shaded_hits;
-    out->paths = h.paths;
+    std::memset(out, 0, sizeof *out);
+    for (const RtCountersDev &s : h) {
+        out->rays += s.rays;
+        out->node_visits += s.node_visits;
+        out->tri_tests += s.tri_tests;
+        out->shaded_hits += s.shaded_hits;
+        out->paths += s.paths;
+    }
     return RT_OK;
 }
 
@@ -677,7 +714,7 @@ int rt_counters_reset(rt_ctx *c) {
     if (!c) return RT_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
-    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(RtCountersDev), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(RtCountersDev) * RT_COUNTER_SHARDS, c->stream));
     return RT_OK;
 }
 
@@ -692,17 +729,14 @@ int rt_timings_read(rt_ctx *c, rt_timings *out, int reset) {
     int rc = bind(c);
     if (rc) return rc;
     if ((rc = drainSpans(c))) return rc;
-    out->trace_ms = c->accMs[TK_TRACE];
-    out->trace_launches = c->accN[TK_TRACE];
-    out->filter_ms = c->accMs[TK_FILTER];
-    out->filter_launches = c->accN[TK_FILTER];
-    out->tonemap_ms = c->accMs[TK_TONEMAP];
-    out->tonemap_launches = c->accN[TK_TONEMAP];
-    if (reset)
-        for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < RT_TIME_KINDS; ++k) {
+        out->ms[k] = c->accMs[k];
+        out->launches[k] = c->accN[k];
+        if (reset) {
             c->accMs[k] = 0;
             c->accN[k] = 0;
         }
+    }
     return RT_OK;
 }
 

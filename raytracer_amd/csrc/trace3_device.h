@@ -172,6 +172,52 @@ __device__ __forceinline__ float randomTriangleAreaDirectionPDF(f3 p, const Ligh
     return flag * len2 / fabsf(dot(d, n));
 }
 
+// ---------------------------------------------------------------- leaf test
+// intersectTriangle (geometry.glsl:31-51) on one {v0, e1, e2} record; e1, e2 were subtracted at upload
+// with the same fp32 operations.  Updates the closest hit with the strict `<` of trace3.cs:177.
+__device__ __forceinline__ void testTriangle(const float4 a0, const float4 a1, const float4 a2, int i, f3 origin,
+                                             f3 dir, float &nearest, int &hitTri, float &hitT, float &hitU,
+                                             float &hitV) {
+    const f3 v0 = xyz(a0), e1 = xyz(a1), e2 = xyz(a2);
+    const f3 pvec = cross(dir, e2);
+    const float det = dot(e1, pvec);
+    if (det < 0.0f) return;
+    const f3 tvec = origin - v0;
+    const float u = dot(tvec, pvec);
+    if (u < 0.0f || u > det) return;
+    const f3 qvec = cross(tvec, e1);
+    const float v = dot(dir, qvec);
+    if (v < 0.0f || (u + v) > det) return;
+    const float invDet = 1.0f / det;
+    const float t = dot(e2, qvec) * invDet;
+    if (t >= 0.0f && t < nearest) {
+        nearest = t;
+        hitT = t;
+        hitU = u * invDet;
+        hitV = v * invDet;
+        hitTri = i;
+    }
+}
+
+// intersectTriangles (trace3.cs:172-186) over [first, end): triangles are tested strictly in index
+// order, four records (12 aligned 16-byte loads) are requested before the first of them is tested so
+// that the load latency of a leaf is paid once per four triangles instead of once per triangle.
+__device__ __forceinline__ void testLeaf(const float4 *__restrict__ tris48, int first, int end, f3 origin, f3 dir,
+                                         float &nearest, int &hitTri, float &hitT, float &hitU, float &hitV) {
+    for (int i = first; i < end; i += 4) {
+        const int last = end - 1;
+        const int i1 = min(i + 1, last), i2 = min(i + 2, last), i3 = min(i + 3, last);
+        const float4 a0 = tris48[3 * i], a1 = tris48[3 * i + 1], a2 = tris48[3 * i + 2];
+        const float4 b0 = tris48[3 * i1], b1 = tris48[3 * i1 + 1], b2 = tris48[3 * i1 + 2];
+        const float4 c0 = tris48[3 * i2], c1 = tris48[3 * i2 + 1], c2 = tris48[3 * i2 + 2];
+        const float4 d0 = tris48[3 * i3], d1 = tris48[3 * i3 + 1], d2 = tris48[3 * i3 + 2];
+        testTriangle(a0, a1, a2, i, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+        if (i + 1 < end) testTriangle(b0, b1, b2, i + 1, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+        if (i + 2 < end) testTriangle(c0, c1, c2, i + 2, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+        if (i + 3 < end) testTriangle(d0, d1, d2, i + 3, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+    }
+}
+
 // ---------------------------------------------------------------- traversal
 // intersectGeometry's loop (trace3.cs:226-269) + intersectTriangles (:172-186).
 // Returns false when the MAX_FOLLOWS abort was taken (trace3.cs:228-234).
@@ -218,31 +264,8 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
             }
         }
         if (leafCount <= 0) break;
-        const int leafEnd = leafFirst + leafCount;
-        for (int i = leafFirst; i < leafEnd; i++) {
-            const float4 a0 = sc.tris48[3 * i], a1 = sc.tris48[3 * i + 1], a2 = sc.tris48[3 * i + 2];
-            tests++;
-            // intersectTriangle, geometry.glsl:31-51 (e1, e2 pre-subtracted at upload: same fp32 values)
-            const f3 v0 = xyz(a0), e1 = xyz(a1), e2 = xyz(a2);
-            const f3 pvec = cross(dir, e2);
-            const float det = dot(e1, pvec);
-            if (det < 0.0f) continue;
-            const f3 tvec = origin - v0;
-            const float u = dot(tvec, pvec);
-            if (u < 0.0f || u > det) continue;
-            const f3 qvec = cross(tvec, e1);
-            const float v = dot(dir, qvec);
-            if (v < 0.0f || (u + v) > det) continue;
-            const float invDet = 1.0f / det;
-            const float t = dot(e2, qvec) * invDet;
-            if (t >= 0.0f && t < nearest) { // intersectTriangles, trace3.cs:177: strict <, lowest index wins ties
-                nearest = t;
-                hit.t = t;
-                hit.u = u * invDet;
-                hit.v = v * invDet;
-                hit.tridx = i;
-            }
-        }
+        testLeaf(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
+        tests += (unsigned)leafCount;
     }
     c.lastIterations = iterations;
     c.rays++;
@@ -420,6 +443,9 @@ __device__ __forceinline__ bool continuePath(PathCtx &c, int bounces, f3 normal,
 }
 
 // wave-wide sum with DPP/permute reductions, one atomic per wave
+__device__ __forceinline__ RtCountersDev *counterShard(RtCountersDev *base) {
+    return base + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (RT_COUNTER_SHARDS - 1));
+}
 __device__ __forceinline__ void waveAdd(unsigned long long *dst, unsigned v) {
     unsigned long long s = v;
 #pragma unroll

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
     }
 
     if (!(p.flags & RT_FLAG_NO_COUNTERS)) {
+        counters = counterShard(counters);
         waveAdd(&counters->rays, c.rays);
         waveAdd(&counters->node_visits, c.visits);
         waveAdd(&counters->tri_tests, c.tests);

@@ -13,6 +13,8 @@ struct WfSample { // per-sample uniforms of a batch (what differs between succes
 struct WfParams {
     float eye[3], ray00[3], ray01[3], ray10[3], ray11[3];
     int maxBounces, numEmitters, maxFollows, flags, batch;
+    int refillLanes;       // idle lanes of a wave that trigger a refill from the ray queue (64 = only when all are idle)
+    int extendBlocksPerCU; // persistent 256-thread blocks per CU of the extend kernel
     WfSample s[WF_MAX_BATCH];
 };
 
@@ -27,8 +29,10 @@ struct WfBuffers {
     uint2 *pixSample;   // pixel index, sample index
     int4 *pathStats;    // rays, visits, tests (RT_FLAG_PIXEL_STATS)
     // ray queue: slot = kind * capacity + queue position
-    float4 *rayO;       // origin.xyz, valid (1.0 / 0.0)
-    float4 *rayD;       // dir.xyz
+    // origins / directions are double-buffered by stage parity: logic(b) reads the rays of stage b
+    // (the continuation ray that produced its hit) while it writes the rays of stage b+1
+    float4 *rayO[2];    // origin.xyz, valid (1.0 / 0.0)
+    float4 *rayD[2];    // dir.xyz
     int4 *rayHit;       // tridx, bits(t), bits(u), bits(v)
     int2 *rayWork;      // visits, tests of that traversal
     int *queue[2];      // path ids, ping-pong
@@ -39,7 +43,9 @@ struct WfBuffers {
 };
 
 hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfParams &p, const WfBuffers &wf,
-                             const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream);
+                             const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream,
+                             void *profileCtx);
+void rtMarkKernel(void *ctxOpaque, int kind, bool begin);
 // bytes of device memory per unit of capacity (one path slot) and per (sample, tile pixel)
 size_t rtWavefrontBytesPerPath();
 

@@ -58,6 +58,7 @@ __device__ __forceinline__ PathCtx makeCtx(const WfParams &p, int x, int y, int 
 __device__ __forceinline__ void flushCounters(const WfParams &p, RtCountersDev *counters, const PathCtx &c,
                                               unsigned paths) {
     if (p.flags & RT_FLAG_NO_COUNTERS) return;
+    counters = counterShard(counters);
     waveAdd(&counters->rays, c.rays);
     waveAdd(&counters->node_visits, c.visits);
     waveAdd(&counters->tri_tests, c.tests);
@@ -123,8 +124,8 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
         wf.L_seed[slot] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
         wf.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
         const size_t r = (size_t)2 * wf.capacity + slot;
-        wf.rayO[r] = make_float4(p.eye[0], p.eye[1], p.eye[2], 1.0f);
-        wf.rayD[r] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+        wf.rayO[0][r] = make_float4(p.eye[0], p.eye[1], p.eye[2], 1.0f);
+        wf.rayD[0][r] = make_float4(dir.x, dir.y, dir.z, 0.0f);
         wf.rayHit[r] = make_int4(h.tridx, __float_as_int(h.t), __float_as_int(h.u), __float_as_int(h.v));
         if (p.flags & RT_FLAG_PIXEL_STATS) wf.pathStats[slot] = make_int4((int)c.rays, (int)c.visits, (int)c.tests, 0);
     }
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
                 // the hit of this bounce: result of the continuation (or primary) ray
                 const size_t r = 2 * cap + i;
                 const int4 hr = wf.rayHit[r];
-                const float4 ro = wf.rayO[r], rd = wf.rayD[r];
+                const float4 ro = wf.rayO[bounce & 1][r], rd = wf.rayD[bounce & 1][r];
                 const f3 origin = F3(ro.x, ro.y, ro.z), dir = F3(rd.x, rd.y, rd.z);
                 if (wantStats && bounce > 0) {
                     const int2 w2 = wf.rayWork[r];
@@ -265,48 +266,132 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
             qout[slot] = pid;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                wf.rayO[k * cap + slot] = rO[k];
-                wf.rayD[k * cap + slot] = rD[k];
+                wf.rayO[(bounce + 1) & 1][k * cap + slot] = rO[k];
+                wf.rayD[(bounce + 1) & 1][k * cap + slot] = rD[k];
             }
         }
     }
-    if (!(p.flags & RT_FLAG_NO_COUNTERS)) waveAdd(&counters->shaded_hits, shaded);
+    if (!(p.flags & RT_FLAG_NO_COUNTERS)) waveAdd(&counterShard(counters)->shaded_hits, shaded);
 }
 
 // ------------------------------------------------------------------------------------------ extend
-// Persistent waves: each wave takes 64 consecutive rays of the stage's queue with one atomic, walks
-// them, stores the hits, and comes back for more until the queue is drained.
+// Persistent waves.  A wave keeps 64 ray slots; when `refillLanes` of its lanes have finished their ray
+// the idle lanes take the next rays of the stage's queue with ONE atomic for the whole wave.  Measured
+// on MI355X (room.obj 1080p, 116 M secondary rays): refilling only when all 64 lanes are idle (the
+// default, refillLanes = 64) is fastest, 53 ms against 61 ms at 32 or 20 idle lanes and 95 ms at 8 — a
+// wave that takes 64 CONSECUTIVE queue entries gets rays of neighbouring pixels, which read the same
+// nodes and triangles; topping lanes up one by one mixes unrelated rays into the wave, and the loss of
+// coalescing in the vector L1 costs more than the idle lanes did.  Inside, the walk is the same "while-while" as traverse() in trace3_device.h —
+// per ray, node visits and triangle tests happen in the reference's order — kept as resumable state.
+
 __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams p, WfBuffers wf, int stage,
-                                                           RtCountersDev *counters) {
+                                                           int refillLanes, RtCountersDev *counters) {
     const int n = min(wf.counts[stage], wf.capacity);
     const int total = 3 * n;
     const size_t cap = (size_t)wf.capacity;
     const int lane = threadIdx.x & 63;
-    PathCtx c = makeCtx(p, 0, 0, 0, 0);
+    const unsigned long long lanesBelow = (1ull << lane) - 1ull;
+    const float4 *rayO = wf.rayO[stage & 1], *rayD = wf.rayD[stage & 1];
+    const bool wantWork = (p.flags & RT_FLAG_PIXEL_STATS) != 0;
+    int *cursor = &wf.counts[32 + stage];
+
+    // per-lane ray state
+    bool active = false;
+    size_t slot = 0;
+    f3 origin = F3(0, 0, 0), dir = F3(0, 0, 0), invdir = F3(0, 0, 0);
+    bool ltx = false, lty = false, ltz = false;
+    int next = -1, iterations = 0, hitTri = -1;
+    unsigned tests = 0;
+    float nearest = 0.0f, hitT = 0.0f, hitU = 0.0f, hitV = 0.0f;
+    // totals for the global counters
+    unsigned cRays = 0, cVisits = 0, cTests = 0;
+    bool exhausted = total <= 0;
+
     for (;;) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&wf.counts[32 + stage], 64);
-        base = __shfl(base, 0, 64);
-        if (base >= total) break;
-        const int w = base + lane;
-        if (w < total) {
-            const int kind = w / n, j = w - kind * n;
-            const size_t r = kind * cap + j;
-            const float4 ro = wf.rayO[r];
-            if (ro.w != 0.0f) {
-                const float4 rd = wf.rayD[r];
-                const f3 dir = F3(rd.x, rd.y, rd.z);
-                Hit h;
-                const unsigned v0 = c.visits, t0 = c.tests;
-                traverse(sc, c, F3(ro.x, ro.y, ro.z), dir, rcp3(dir), h);
-                wf.rayHit[r] = make_int4(h.tridx, __float_as_int(h.t), __float_as_int(h.u), __float_as_int(h.v));
-                if (p.flags & RT_FLAG_PIXEL_STATS) wf.rayWork[r] = make_int2((int)(c.visits - v0), (int)(c.tests - t0));
-            } else if (p.flags & RT_FLAG_PIXEL_STATS) {
-                wf.rayWork[r] = make_int2(0, 0);
+        const unsigned long long idle = __ballot(!active);
+        if (!exhausted && (idle == ~0ull || __popcll(idle) >= refillLanes)) {
+            const int want = __popcll(idle);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(cursor, want);
+            base = __shfl(base, 0, 64);
+            if (base + want >= total) exhausted = true;
+            if (!active) {
+                const int w = base + __popcll(idle & lanesBelow);
+                if (w < total) {
+                    const int kind = w / n, j = w - kind * n;
+                    slot = kind * cap + j;
+                    const float4 ro = rayO[slot];
+                    if (ro.w != 0.0f) {
+                        const float4 rd = rayD[slot];
+                        origin = F3(ro.x, ro.y, ro.z);
+                        dir = F3(rd.x, rd.y, rd.z);
+                        invdir = rcp3(dir);
+                        ltx = invdir.x < 0.0f;
+                        lty = invdir.y < 0.0f;
+                        ltz = invdir.z < 0.0f;
+                        next = 0;
+                        nearest = __builtin_inff();
+                        iterations = 0;
+                        tests = 0;
+                        hitTri = -1;
+                        hitT = hitU = hitV = 0.0f;
+                        active = true;
+                    } else if (wantWork) {
+                        wf.rayWork[slot] = make_int2(0, 0); // a ray that was never cast (path ended by the roulette)
+                    }
+                }
             }
         }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // phase 1: walk nodes until this lane holds a leaf it entered, or has no node left
+        int leafFirst = 0, leafCount = 0;
+        while (active && next != -1 && leafCount == 0) {
+            iterations++;
+            if (iterations > p.maxFollows) { // trace3.cs:228-234
+                hitTri = -1;
+                next = -1;
+                break;
+            }
+            const float4 b0 = sc.boxes[2 * next], b1 = sc.boxes[2 * next + 1];
+            const int hitNext = __float_as_int(b0.w), missNext = __float_as_int(b1.w);
+            const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
+                        m1z = (b0.z - origin.z) * invdir.z;
+            const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
+                        m2z = (b1.z - origin.z) * invdir.z;
+            const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
+            const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
+            const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f; // geometry.glsl:66-76
+            if (!boxHit || mint > nearest) {
+                next = missNext;
+            } else {
+                const int2 leaf = sc.leaves[next];
+                leafFirst = leaf.x;
+                leafCount = leaf.y;
+                next = hitNext;
+            }
+        }
+        // phase 2: the leaf's triangles (geometry.glsl:31-51, trace3.cs:172-186)
+        if (active && leafCount > 0) {
+            testLeaf(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+            tests += (unsigned)leafCount;
+        } else if (active && next == -1) {
+            // the walk is over: publish the closest hit and free the lane
+            wf.rayHit[slot] = make_int4(hitTri, __float_as_int(hitT), __float_as_int(hitU), __float_as_int(hitV));
+            if (wantWork) wf.rayWork[slot] = make_int2(iterations, (int)tests);
+            cRays++;
+            cVisits += (unsigned)iterations;
+            cTests += tests;
+            active = false;
+        }
     }
-    c.shaded = 0;
+    PathCtx c = makeCtx(p, 0, 0, 0, 0);
+    c.rays = cRays;
+    c.visits = cVisits;
+    c.tests = cTests;
     flushCounters(p, counters, c, 0u);
 }
 
@@ -336,10 +421,11 @@ __global__ __launch_bounds__(256) void rt_wf_blend_kernel(RtImages img, WfParams
 }
 
 // ------------------------------------------------------------------------------------------ host
-size_t rtWavefrontBytesPerPath() { return 6 * 16 + 8 + 16 + 3 * (16 + 16 + 16 + 8) + 2 * 4; }
+size_t rtWavefrontBytesPerPath() { return 6 * 16 + 8 + 16 + 3 * (4 * 16 + 16 + 8) + 2 * 4; }
 
 hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfParams &p, const WfBuffers &wf,
-                             const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream) {
+                             const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream,
+                             void *prof) {
     const int tw = tile.x1 - tile.x0, th = tile.y1 - tile.y0;
     if (tw <= 0 || th <= 0 || p.batch <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(wf.counts, 0, 64 * sizeof(int), stream);
@@ -347,17 +433,26 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     const int tilesX = (tw + 15) / 16, tilesY = (th + 15) / 16;
     const int ntiles = tilesX * tilesY * p.batch;
     const int nblocks = ((ntiles + 7) / 8) * 8;
+    if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, true);
     hipLaunchKernelGGL(rt_wf_primary_kernel, dim3(nblocks), dim3(256), 0, stream, sc, img, p, wf, tile, tilesX, tilesY,
                        xcdRemap, counters);
+    if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, false);
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
-    const int logicBlocks = 256 * 4, extendBlocks = 256 * 6;
+    const int logicBlocks = 256 * 4, extendBlocks = 256 * p.extendBlocksPerCU;
     for (int b = 0; b <= p.maxBounces; ++b) {
+        if (prof) rtMarkKernel(prof, RT_TIME_WF_LOGIC, true);
         hipLaunchKernelGGL(rt_wf_logic_kernel, dim3(logicBlocks), dim3(256), 0, stream, sc, img, p, wf, tile, b, counters);
-        if (b < p.maxBounces)
-            hipLaunchKernelGGL(rt_wf_extend_kernel, dim3(extendBlocks), dim3(256), 0, stream, sc, p, wf, b + 1, counters);
+        if (prof) rtMarkKernel(prof, RT_TIME_WF_LOGIC, false);
+        if (b < p.maxBounces) {
+            if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, true);
+            hipLaunchKernelGGL(rt_wf_extend_kernel, dim3(extendBlocks), dim3(256), 0, stream, sc, p, wf, b + 1, p.refillLanes, counters);
+            if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, false);
+        }
     }
     int blendBlocks = (tw * th + 255) / 256;
     if (blendBlocks > 4096) blendBlocks = 4096;
+    if (prof) rtMarkKernel(prof, RT_TIME_WF_BLEND, true);
     hipLaunchKernelGGL(rt_wf_blend_kernel, dim3(blendBlocks), dim3(256), 0, stream, img, p, wf, tile);
+    if (prof) rtMarkKernel(prof, RT_TIME_WF_BLEND, false);
     return hipGetLastError();
 }

@@ -44,10 +44,22 @@ class Counters(ctypes.Structure):
                 ("shaded_hits", ctypes.c_uint64), ("paths", ctypes.c_uint64)]
 
 
+(TIME_TRACE, TIME_FILTER, TIME_TONEMAP, TIME_WF_PRIMARY, TIME_WF_LOGIC, TIME_WF_EXTEND, TIME_WF_BLEND,
+ TIME_PER_PIXEL) = range(8)
+TIME_NAMES = ["trace", "filter", "tonemap", "wf_primary", "wf_logic", "wf_extend", "wf_blend", "per_pixel"]
+
+
 class Timings(ctypes.Structure):
-    _fields_ = [("trace_ms", ctypes.c_double), ("trace_launches", ctypes.c_uint64),
-                ("filter_ms", ctypes.c_double), ("filter_launches", ctypes.c_uint64),
-                ("tonemap_ms", ctypes.c_double), ("tonemap_launches", ctypes.c_uint64)]
+    _fields_ = [("ms", ctypes.c_double * 8), ("launches", ctypes.c_uint64 * 8)]
+
+    trace_ms = property(lambda s: s.ms[0])
+    trace_launches = property(lambda s: s.launches[0])
+    filter_ms = property(lambda s: s.ms[1])
+    filter_launches = property(lambda s: s.launches[1])
+    tonemap_ms = property(lambda s: s.ms[2])
+
+    def as_dict(self):
+        return {n: (self.ms[i], int(self.launches[i])) for i, n in enumerate(TIME_NAMES) if self.launches[i]}
 
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_upload", "rt_set_table", "rt_resize",

@@ -85,8 +85,8 @@ int main(int argc, char **argv) {
         rtCheck(rtApi().timings_read(rtCurrentContext(), &t, 0), "rt_timings_read");
         const rt_counters c = tracer.counters();
         std::printf("%d x %d, %d frames, %d bounces: trace %.3f ms, filter %.3f ms (%d passes); %llu rays, %.1f Mrays/s\n",
-                    WIDTH, HEIGHT, frames, bounces, t.trace_ms, t.filter_ms, (int)t.filter_launches,
-                    (unsigned long long)c.rays, t.trace_ms > 0 ? c.rays / (t.trace_ms * 1e3) : 0.0);
+                    WIDTH, HEIGHT, frames, bounces, t.ms[RT_TIME_TRACE], t.ms[RT_TIME_FILTER], (int)t.launches[RT_TIME_FILTER],
+                    (unsigned long long)c.rays, t.ms[RT_TIME_TRACE] > 0 ? c.rays / (t.ms[RT_TIME_TRACE] * 1e3) : 0.0);
         rtReleaseCurrentContext();
     } catch (const std::exception &e) {
         std::cerr << e.what() << std::endl;

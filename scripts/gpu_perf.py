@@ -19,6 +19,7 @@ def run(name, W, H, spp=4, mb=5, iters=5, reps=5, **kw):
     tr = tm.trace_ms / reps
     print(f"{str(kw):28s} {name:8s} {W}x{H} spp{spp} mb{mb}: frame wall {wall*1e3:8.3f} ms | trace {tr:8.3f} ms ({tr/spp:7.3f}/launch) filter {tm.filter_ms/reps:6.3f} ms | "
           f"rays/frame {c.rays//reps:>10d} visits/ray {c.node_visits/max(c.rays,1):6.1f} tests/ray {c.tri_tests/max(c.rays,1):6.1f} | {c.rays/reps/tr/1e3:8.1f} Mrays/s (trace only)", flush=True)
+    print("      per-kernel ms/frame:", {k: round(v[0]/reps, 3) for k, v in tm.as_dict().items()}, flush=True)
     ctx.close()
 
 if __name__ == "__main__":

@@ -95,7 +95,8 @@ def test_trace_against_oracle(ctx, scene, w, h, spp, mb):
     assert abs(int(got["stats"][..., 0].sum()) - int(ref["stats"][..., 0].sum())) <= 0.002 * ref["stats"][..., 0].sum()
 
 
-@pytest.mark.parametrize("scene,w,h,spp,mb", [("room", 120, 90, 3, 5), ("scene", 400, 225, 4, 5), ("teapot", 96, 64, 2, 0)])
+@pytest.mark.parametrize("scene,w,h,spp,mb", [("room", 120, 90, 3, 5), ("scene", 400, 225, 4, 5), ("teapot", 96, 64, 2, 0),
+                                               ("room", 800, 450, 4, 5)])  # the last: queues larger than one grid pass
 def test_schedules_are_bit_identical(ctx, scene, w, h, spp, mb):
     """Wavefront pipeline with concurrent samples, wavefront one sample at a time, and the
     one-lane-per-path kernel: every image and every counter must be identical."""
