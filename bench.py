@@ -124,9 +124,10 @@ def main():
 
     cnt = ctx.counters()
     tm = ctx.timings()
+    K = hiplib
     local = torch.tensor([elapsed, float(cnt.rays), float(cnt.node_visits), float(cnt.tri_tests),
-                          float(cnt.shaded_hits), float(cnt.paths), tm.trace_ms, float(tm.trace_launches),
-                          tm.filter_ms, float(tm.filter_launches)], dtype=torch.float64, device=device)
+                          float(cnt.shaded_hits), float(cnt.paths)] + [tm.ms[i] for i in range(8)],
+                         dtype=torch.float64, device=device)
     if dist is not None:
         tmax = local.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -145,23 +146,43 @@ def main():
     rays, visits, tests, hits, paths = sums[1:6]
     ms_per_step = elapsed * 1e3 / a.steps
     mrays = rays / elapsed / 1e6
-    # roofline of the dominant kernel (rt_trace3_kernel), per launch, from HIP events on its stream.
-    # Algorithmic bytes: 48 B per node visit + 48 B per triangle test + 160 B per shaded
-    # hit + 28 B written per pixel-sample (+16 B read when blending, i.e. for 3 of the 4 samples).
-    launches = max(sums[7], 1.0)
-    blend_reads = paths * 16.0 * (a.spp - 1) / max(a.spp, 1)
-    alg_bytes = 48.0 * visits + 48.0 * tests + 160.0 * hits + 28.0 * paths + blend_reads
-    trace_ms_rank0 = local[6].item() / max(local[7].item(), 1.0)       # avg launch duration on this rank
-    alg_bytes_per_launch_rank0 = (48.0 * cnt.node_visits + 48.0 * cnt.tri_tests + 160.0 * cnt.shaded_hits +
-                                  28.0 * cnt.paths + cnt.paths * 16.0 * (a.spp - 1) / max(a.spp, 1)) / max(local[7].item(), 1.0)
-    achieved = alg_bytes_per_launch_rank0 / (trace_ms_rank0 * 1e-3) / 1e9 if trace_ms_rank0 > 0 else 0.0
-    ops_per_launch = (25.0 * cnt.node_visits + 51.0 * cnt.tri_tests) / max(local[7].item(), 1.0)
+    # Roofline of the dominant kernel, per launch, from HIP events recorded on the kernel's own stream
+    # (rt_profile).  The dominant kernel is whichever of the pipeline's kernels took most device time on
+    # this rank; its algorithmic bytes follow SURVEY.md 8(d): 48 B per node visit + 48 B per triangle
+    # test it performed (+ 160 B per shaded hit and the per-pixel-sample image bytes for kernels that do those).
+    kernel_ms = {K.TIME_NAMES[i]: tm.ms[i] for i in range(3, 8) if tm.launches[i]}
+    dominant = max(kernel_ms, key=kernel_ms.get)
+    didx = K.TIME_NAMES.index(dominant)
+    launches = int(tm.launches[didx])
+    avg_launch_ms = tm.ms[didx] / max(launches, 1)
+    primary_rays = float(cnt.paths)
+    sec_visits, sec_tests = cnt.node_visits - cnt.primary_node_visits, cnt.tri_tests - cnt.primary_tri_tests
+    if dominant == "wf_extend":    # every non-primary traversal; reads a 32 B ray, writes a 16 B hit per ray
+        alg_bytes = 48.0 * (sec_visits + sec_tests) + 48.0 * (cnt.rays - primary_rays)
+        ops = 25.0 * sec_visits + 51.0 * sec_tests
+        kname = "rt_wf_extend_kernel"
+    elif dominant == "per_pixel":
+        alg_bytes = (48.0 * (cnt.node_visits + cnt.tri_tests) + 160.0 * cnt.shaded_hits + 28.0 * cnt.paths +
+                     16.0 * cnt.paths * (a.spp - 1) / max(a.spp, 1))
+        ops = 25.0 * cnt.node_visits + 51.0 * cnt.tri_tests
+        kname = "rt_trace3_kernel"
+    elif dominant == "wf_primary":  # primary traversals + G-buffer / radiance writes (28 B per pixel-sample)
+        alg_bytes = 48.0 * (cnt.primary_node_visits + cnt.primary_tri_tests) + 28.0 * cnt.paths
+        ops = 25.0 * cnt.primary_node_visits + 51.0 * cnt.primary_tri_tests
+        kname = "rt_wf_primary_kernel"
+    else:                           # logic / blend: path-state streaming, ~300 B per queued path and stage
+        alg_bytes = 160.0 * cnt.shaded_hits + 300.0 * cnt.shaded_hits
+        ops = 0.0
+        kname = "rt_" + dominant + "_kernel"
+    alg_bytes_per_launch = alg_bytes / max(launches, 1)
+    achieved = alg_bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    tops = ops / max(launches, 1) / (avg_launch_ms * 1e-3) / 1e12 if avg_launch_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get(f"{a.scene}_{W}x{H}_trace3_bytes_per_launch")
+                traffic = json.load(f).get(f"{a.scene}_{W}x{H}_{kname}_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
@@ -174,22 +195,21 @@ def main():
                                f"a-trous filter, SURVEY 8(d) auto camera + harness quad light"
                                f" (BASELINE.json configs[2])",
                    "triangles": wl.info.num_triangles, "nodes": wl.info.num_nodes, "emitters": wl.num_emitters,
+                   "schedule": "wavefront pipeline, samples of a frame traced concurrently (rt_trace_batch)",
                    "parallelism": f"{world} x screen-space row strips, halo {backend.halo} rows, gather to rank 0"},
         "rays_per_frame": rays / a.steps, "node_visits_per_frame": visits / a.steps,
         "tri_tests_per_frame": tests / a.steps,
-        "trace_ms_per_frame_max_rank": round(maxs[6] / a.steps, 4),
-        "filter_ms_per_frame_max_rank": round(maxs[8] / a.steps, 4),
-        "roofline": {"bound": "hbm", "kernel": "rt_trace3_kernel", "achieved": round(achieved, 2),
+        "kernel_ms_per_frame_max_rank": {K.TIME_NAMES[i]: round(maxs[6 + i] / a.steps, 4) for i in range(8)
+                                         if maxs[6 + i] > 0},
+        "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                     "traffic": traffic, "avg_launch_ms": round(trace_ms_rank0, 4),
-                     "algorithmic_bytes_per_launch": round(alg_bytes_per_launch_rank0),
-                     "note": "scene + BVH (<1 MB) are L2-resident, so the algorithmic bytes are served by L2, not HBM; "
-                             "the kernel is bound by fp32 VALU issue and divergence (see valu)",
-                     "valu": {"achieved_Tops": round(ops_per_launch / (trace_ms_rank0 * 1e-3) / 1e12, 4)
-                              if trace_ms_rank0 > 0 else 0.0,
-                              "peak_Tops_no_fma": VALU_PEAK_TOPS_NOFMA,
-                              "frac": round(ops_per_launch / (trace_ms_rank0 * 1e-3) / 1e12 / VALU_PEAK_TOPS_NOFMA, 4)
-                              if trace_ms_rank0 > 0 else 0.0,
+                     "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches,
+                     "algorithmic_bytes_per_launch": round(alg_bytes_per_launch),
+                     "note": "scene + BVH (<1 MB) stay resident in every XCD's L2, so these algorithmic bytes are "
+                             "served by L1/L2 and not by HBM (traffic = measured HBM bytes); the kernel is limited by "
+                             "vector-L1 gather throughput, fp32 VALU issue and divergence (see valu)",
+                     "valu": {"achieved_Tops": round(tops, 4), "peak_Tops_no_fma": VALU_PEAK_TOPS_NOFMA,
+                              "frac": round(tops / VALU_PEAK_TOPS_NOFMA, 4),
                               "ops_model": "25 per node visit + 51 per triangle test (SURVEY 8(d))"}},
     }
     if world == 1 and not a.no_cpu_baseline:

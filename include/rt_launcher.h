@@ -112,7 +112,9 @@ typedef struct rt_counters {
     uint64_t node_visits; /* Σ `iterations` (trace3.cs:227)                                            */
     uint64_t tri_tests;   /* Σ intersectTriangle calls (trace3.cs:177)                                 */
     uint64_t shaded_hits; /* closest hits that were shaded                                              */
-    uint64_t paths;       /* pixel-samples                                                              */
+    uint64_t paths;       /* pixel-samples (= primary rays)                                             */
+    uint64_t primary_node_visits; /* the part of node_visits done by primary rays                      */
+    uint64_t primary_tri_tests;   /* the part of tri_tests done by primary rays                        */
 } rt_counters;
 
 /* Accumulated device time per kernel family, measured with HIP events on the context's stream while

@@ -68,8 +68,8 @@ struct RtImages {
 // first version of the trace kernels milliseconds per launch).
 #define RT_COUNTER_SHARDS 256
 struct __attribute__((aligned(128))) RtCountersDev {
-    unsigned long long rays, node_visits, tri_tests, shaded_hits, paths;
-    unsigned long long pad[11];
+    unsigned long long rays, node_visits, tri_tests, shaded_hits, paths, primary_visits, primary_tests;
+    unsigned long long pad[9];
 };
 static_assert(sizeof(RtCountersDev) == 128, "one shard per 128-byte line");
 

@@ -706,6 +706,8 @@ int rt_counters_read(rt_ctx *c, rt_counters *out) {
         out->tri_tests += s.tri_tests;
         out->shaded_hits += s.shaded_hits;
         out->paths += s.paths;
+        out->primary_node_visits += s.primary_visits;
+        out->primary_tri_tests += s.primary_tests;
     }
     return RT_OK;
 }

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
     c.maxFollows = p.maxFollows > 0 ? p.maxFollows : 1000;
     c.rays = c.visits = c.tests = c.shaded = 0;
     c.lastIterations = 0;
+    unsigned primaryVisits = 0, primaryTests = 0;
 
     if (active) {
         const int W = img.width, H = img.height;
@@ -78,6 +79,8 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
                 const f3 n = found ? SI.normal : F3(0, 0, 0), q = found ? SI.point : F3(0, 0, 0);
                 img.normal[pix] = snorm8(n.x) | (snorm8(n.y) << 8) | (snorm8(n.z) << 16);
                 img.pos[pix] = make_uint2(pack_half2_rtz(q.x, q.y), pack_half2_rtz(q.z, 1.0f));
+                primaryVisits = c.visits;
+                primaryTests = c.tests;
                 if (p.flags & RT_FLAG_AUX) {
                     img.tridx[pix] = SI.tridx;
                     img.visits[pix] = c.lastIterations;
@@ -124,6 +127,8 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
         waveAdd(&counters->tri_tests, c.tests);
         waveAdd(&counters->shaded_hits, c.shaded);
         waveAdd(&counters->paths, active ? 1u : 0u);
+        waveAdd(&counters->primary_visits, primaryVisits);
+        waveAdd(&counters->primary_tests, primaryTests);
     }
 }
 

@@ -130,6 +130,10 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
         if (p.flags & RT_FLAG_PIXEL_STATS) wf.pathStats[slot] = make_int4((int)c.rays, (int)c.visits, (int)c.tests, 0);
     }
     flushCounters(p, counters, c, active ? 1u : 0u);
+    if (!(p.flags & RT_FLAG_NO_COUNTERS)) {
+        waveAdd(&counterShard(counters)->primary_visits, c.visits);
+        waveAdd(&counterShard(counters)->primary_tests, c.tests);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ logic

@@ -41,7 +41,8 @@ class TraceParams(ctypes.Structure):
 
 class Counters(ctypes.Structure):
     _fields_ = [("rays", ctypes.c_uint64), ("node_visits", ctypes.c_uint64), ("tri_tests", ctypes.c_uint64),
-                ("shaded_hits", ctypes.c_uint64), ("paths", ctypes.c_uint64)]
+                ("shaded_hits", ctypes.c_uint64), ("paths", ctypes.c_uint64),
+                ("primary_node_visits", ctypes.c_uint64), ("primary_tri_tests", ctypes.c_uint64)]
 
 
 (TIME_TRACE, TIME_FILTER, TIME_TONEMAP, TIME_WF_PRIMARY, TIME_WF_LOGIC, TIME_WF_EXTEND, TIME_WF_BLEND,
