@@ -26,6 +26,22 @@ class OrcTraceParams(ctypes.Structure):
                 ("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32), ("y1", ctypes.c_int32)]
 
 
+class OrcAnalyticParams(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("eye", ctypes.c_float * 3), ("ray00", ctypes.c_float * 3), ("ray01", ctypes.c_float * 3),
+                ("ray10", ctypes.c_float * 3), ("ray11", ctypes.c_float * 3),
+                ("time", ctypes.c_float), ("blend_factor", ctypes.c_float),
+                ("importance_sampled", ctypes.c_int32), ("multiple_importance_sampled", ctypes.c_int32),
+                ("use_blue_noise", ctypes.c_int32), ("frame_index", ctypes.c_int32),
+                ("phong_exponent", ctypes.c_float), ("specular_factor", ctypes.c_float), ("roughness", ctypes.c_float),
+                ("sobol", ctypes.c_void_p), ("scramble", ctypes.c_void_p), ("ranking", ctypes.c_void_p),
+                ("ltc1", ctypes.c_void_p), ("ltc2", ctypes.c_void_p),
+                ("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32), ("y1", ctypes.c_int32)]
+
+
+ANALYTIC_KERNELS = {"trace": 0, "trace1": 1, "trace2": 2}
+TABLE_BYTES = {"sobol": 65536, "scramble": 131072, "ranking": 131072, "ltc1": 65536, "ltc2": 65536}
+
 _lib = None
 
 
@@ -38,6 +54,8 @@ def lib():
         vp = ctypes.c_void_p
         L.orc_trace.argtypes = [ctypes.POINTER(OrcScene), ctypes.POINTER(OrcTraceParams), vp, vp, vp, vp, vp, vp]
         L.orc_trace.restype = None
+        L.orc_trace_analytic.argtypes = [ctypes.c_int32, ctypes.POINTER(OrcAnalyticParams), vp, vp, vp, vp]
+        L.orc_trace_analytic.restype = None
         L.orc_filter_pass.argtypes = [ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int32, vp, vp, vp,
                                       ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32]
         L.orc_filter_pass.restype = None
@@ -109,6 +127,44 @@ def trace(scene, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.
                     tridx.ctypes.data, visits.ctypes.data, stats.ctypes.data)
         stats_sum += stats
     return dict(stats_sum=stats_sum, color=color, normal=normal, pos=pos.view(np.float16), tridx=tridx, visits=visits, stats=stats)
+
+
+def trace_analytic(kernel, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.0625, importance=1, mis=1,
+                   use_blue_noise=1, phong_exponent=128.0, specular_factor=0.2, roughness=0.5, tables=None, color=None,
+                   rect=None):
+    """trace.cs / trace1.cs / trace2.cs, `spp` dispatches with the per-frame uniforms of the golden fixtures
+    (time_k, blendFactor_k = k/(k+1), frameIndex = k)."""
+    L = lib()
+    color = np.zeros((height, width, 4), np.float32) if color is None else np.ascontiguousarray(color, np.float32).copy()
+    normal = np.zeros((height, width, 4), np.int8)
+    pos = np.zeros((height, width, 4), np.uint16)
+    objid = np.full((height, width), -2, np.int32)
+    rays = np.asarray(rays, np.float32).reshape(4, 3)
+    p = OrcAnalyticParams()
+    p.width, p.height = width, height
+    p.eye[:] = [float(np.float32(v)) for v in eye]
+    p.ray00[:], p.ray01[:], p.ray10[:], p.ray11[:] = rays[0].tolist(), rays[1].tolist(), rays[2].tolist(), rays[3].tolist()
+    p.importance_sampled, p.multiple_importance_sampled, p.use_blue_noise = int(importance), int(mis), int(use_blue_noise)
+    p.phong_exponent, p.specular_factor, p.roughness = phong_exponent, specular_factor, roughness
+    keep = {}
+    for name, nbytes in TABLE_BYTES.items():
+        b = (tables or {}).get(name)
+        if b is not None:
+            a = np.frombuffer(bytes(b), np.uint8).copy()
+            if a.size != nbytes:
+                raise ValueError(f"table {name}: {a.size} bytes, expected {nbytes}")
+            keep[name] = a
+            setattr(p, name, a.ctypes.data)
+    if rect is not None:
+        p.x0, p.y0, p.x1, p.y1 = rect
+    for k in range(spp):
+        frame = frame0 + k
+        p.time = float(np.float32(time0) + np.float32(dtime) * np.float32(frame))
+        p.blend_factor = float(np.float32(frame) / (np.float32(frame) + np.float32(1.0)))
+        p.frame_index = frame
+        L.orc_trace_analytic(ANALYTIC_KERNELS[kernel], ctypes.byref(p), color.ctypes.data, normal.ctypes.data,
+                             pos.ctypes.data, objid.ctypes.data)
+    return dict(color=color, normal=normal, pos=pos.view(np.float16), tridx=objid)
 
 
 def filter_passes(color, normal, pos, iterations, c_phi0=3.3, n_phi0=1e-2, p_phi0=5.5):

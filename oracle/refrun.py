@@ -25,9 +25,13 @@ def _hexf(x):
 
 def run(scene_buffers, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.0625, max_bounces=5,
         num_emitters=0, importance=1, instrument=True, filter_iters=0, c_phi0=3.3, n_phi0=1e-2, p_phi0=5.5,
-        repeat=1, init_color=None, init_normal=None, init_pos=None, stats_per_sample=False, timeout=3600):
+        repeat=1, init_color=None, init_normal=None, init_pos=None, stats_per_sample=False, timeout=3600,
+        shader="trace3", phong_exponent=128.0, specular_factor=0.2, roughness=0.5, mis=1, use_blue_noise=1,
+        tables=None):
     """scene_buffers: {slot: bytes} for slots 3..10 (missing → zeros). Returns dict of numpy arrays
-    (row 0 = bottom image row, as GL) plus 'trace_ms' / 'filter_ms' lists and 'log'."""
+    (row 0 = bottom image row, as GL) plus 'trace_ms' / 'filter_ms' lists and 'log'.
+    shader: "trace3" (live kernel) | "trace" | "trace1" | "trace2"; tables: {"sobol"|"scramble"|"ranking"|"ltc1"|
+    "ltc2": bytes} for trace1 / trace2 (the reference's res/*.data contents)."""
     if not available():
         raise RuntimeError("reference oracle unavailable (no oracle/_ref/run_ref_shader or no reference dir)")
     names = {3: "nodes", 4: "tris", 5: "mtls", 6: "emitters", 7: "vnormals", 8: "vcentres", 9: "qtable",
@@ -38,7 +42,14 @@ def run(scene_buffers, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dt
                  f"num_emitters={num_emitters}", f"importance={int(importance)}", f"instrument={int(instrument)}",
                  f"filter_iters={filter_iters}", f"c_phi0={_hexf(c_phi0)}", f"n_phi0={_hexf(n_phi0)}",
                  f"p_phi0={_hexf(p_phi0)}", f"repeat={repeat}", f"out={tmp}/o",
-                 f"dump_stats_per_sample={int(stats_per_sample)}"]
+                 f"dump_stats_per_sample={int(stats_per_sample)}", f"shader={shader}",
+                 f"phong_exponent={_hexf(phong_exponent)}", f"specular_factor={_hexf(specular_factor)}",
+                 f"roughness={_hexf(roughness)}", f"mis={int(mis)}", f"use_blue_noise={int(use_blue_noise)}"]
+        for name, b in (tables or {}).items():
+            p = os.path.join(tmp, name + ".tbl")
+            with open(p, "wb") as f:
+                f.write(bytes(b))
+            lines.append(f"{name}={p}")
         for slot, name in names.items():
             b = scene_buffers.get(slot, b"") if scene_buffers else b""
             if b:

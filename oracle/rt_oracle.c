@@ -589,6 +589,432 @@ void orc_trace(const orc_scene *scene, const orc_trace_params *p, float *color, 
     }
 }
 
+/* ------------------------------------------------------------------ analytic kernels
+ * trace.cs (box room), trace1.cs (box room + rectangle light, MIS, blue-noise sampler), trace2.cs (LTC area
+ * lights).  They share random.glsl with trace3; their own PI macros are unparenthesised (trace.cs:33-35,
+ * trace1.cs:60-62), so `x * ONE_OVER_PI` is (x*1.0)/PI and `x * ONE_OVER_2PI` is (x*1.0)/(2*PI): divisions. */
+typedef struct { v3 mn, mx, col; } box_t;
+typedef struct { v3 c, x, y; } rect_t;
+
+/* trace.cs:45-57 == trace1.cs:95-107 */
+static const box_t BOXES_ROOM[11] = {
+    {{-5.0f, -1.0f, -5.0f}, {5.0f, 0.0f, 5.0f}, {0.5f, 0.45f, 0.33f}},
+    {{-5.1f, 0.0f, -5.0f}, {-5.0f, 5.0f, 5.0f}, {0.4f, 0.4f, 0.4f}},
+    {{5.0f, 0.0f, -5.0f}, {5.1f, 5.0f, 5.0f}, {0.4f, 0.4f, 0.4f}},
+    {{-5.0f, 0.0f, -5.1f}, {5.0f, 5.0f, -5.0f}, {0.43f, 0.52f, 0.27f}},
+    {{-5.0f, 0.0f, 5.0f}, {5.0f, 5.0f, 5.1f}, {0.5f, 0.2f, 0.09f}},
+    {{-1.0f, 1.0f, -1.0f}, {1.0f, 1.1f, 1.0f}, {0.3f, 0.23f, 0.15f}},
+    {{-1.0f, 0.0f, -1.0f}, {-0.8f, 1.0f, -0.8f}, {0.4f, 0.3f, 0.15f}},
+    {{-1.0f, 0.0f, 0.8f}, {-0.8f, 1.0f, 1.0f}, {0.4f, 0.3f, 0.15f}},
+    {{0.8f, 0.0f, -1.0f}, {1.0f, 1.0f, -0.8f}, {0.4f, 0.3f, 0.15f}},
+    {{0.8f, 0.0f, 0.8f}, {1.0f, 1.0f, 1.0f}, {0.4f, 0.3f, 0.15f}},
+    {{3.0f, 0.0f, -4.9f}, {3.3f, 2.0f, -4.6f}, {1.0f, 0.0f, 0.0f}},
+};
+/* trace1.cs:109-111 */
+static const rect_t RECT_LIGHT = {{-3.0f, 0.3f, 3.0f}, {6.0f, 0.0f, 0.0f}, {0.0f, -0.2f, 0.05f}};
+/* trace2.cs:33-39 */
+static const box_t BOXES_LTC[5] = {
+    {{-5.0f, -0.1f, -5.0f}, {5.0f, 0.0f, 5.0f}, {0.90f, 0.85f, 0.78f}},
+    {{-5.1f, 0.0f, -5.0f}, {-5.0f, 5.0f, 5.0f}, {1.00f, 0.82f, 0.78f}},
+    {{5.0f, 0.0f, -5.0f}, {5.1f, 5.0f, 5.0f}, {1.00f, 1.00f, 0.90f}},
+    {{-5.0f, 0.0f, -5.1f}, {5.0f, 5.0f, -5.0f}, {0.63f, 0.82f, 0.37f}},
+    {{-5.0f, 0.0f, 5.0f}, {5.0f, 5.0f, 5.1f}, {0.96f, 0.6f, 0.29f}},
+};
+/* trace2.cs:47-64 */
+static const rect_t RECTS_LTC[16] = {
+    {{0.0f, 5.0f, 3.0f}, {0.2f, 0.0f, 0.0f}, {0.0f, -5.0f, 0.0f}},
+    {{-1.0f, 4.0f, 3.0f}, {0.2f, 0.0f, 0.0f}, {0.0f, -4.0f, 0.0f}},
+    {{-2.0f, 3.0f, 3.0f}, {0.2f, 0.0f, 0.0f}, {0.0f, -3.0f, 0.0f}},
+    {{-3.0f, 2.0f, 3.0f}, {0.2f, 0.0f, 0.0f}, {0.0f, -2.0f, 0.0f}},
+    {{-4.0f, 1.0f, 3.0f}, {0.2f, 0.0f, 0.0f}, {0.0f, -1.0f, 0.0f}},
+    {{4.0f, 1.0f, 3.0f}, {0.2f, 0.0f, 0.0f}, {0.0f, -1.0f, 0.0f}},
+    {{3.0f, 2.0f, 3.0f}, {0.2f, 0.0f, 0.0f}, {0.0f, -2.0f, 0.0f}},
+    {{2.0f, 3.0f, 3.0f}, {0.2f, 0.0f, 0.0f}, {0.0f, -3.0f, 0.0f}},
+    {{1.0f, 4.0f, 3.0f}, {0.2f, 0.0f, 0.0f}, {0.0f, -4.0f, 0.0f}},
+    {{4.9f, 4.0f, 4.0f}, {0.0f, 0.0f, -5.0f}, {0.0f, -0.2f, 0.0f}},
+    {{4.9f, 3.0f, 3.0f}, {0.0f, 0.0f, -5.0f}, {0.0f, -0.2f, 0.0f}},
+    {{4.9f, 2.0f, 2.0f}, {0.0f, 0.0f, -5.0f}, {0.0f, -0.2f, 0.0f}},
+    {{4.9f, 1.0f, 1.0f}, {0.0f, 0.0f, -5.0f}, {0.0f, -0.2f, 0.0f}},
+    {{-1.0f, 5.0f, -4.9f}, {0.2f, 0.0f, 0.0f}, {0.0f, -2.0f, 0.0f}},
+    {{0.0f, 3.0f, -4.9f}, {0.2f, 0.0f, 0.0f}, {0.0f, -2.0f, 0.0f}},
+    {{1.0f, 5.0f, -4.9f}, {0.2f, 0.0f, 0.0f}, {0.0f, -2.0f, 0.0f}},
+};
+
+static inline float signf_glsl(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+
+/* trace.cs:59-68 == trace1.cs:124-134 == trace2.cs:196-205 */
+static inline void boxSlabs(v3 origin, v3 dir, const box_t *b, v3 *normal, float *tNear, float *tFar) {
+    v3 tMin = V3((b->mn.x - origin.x) / dir.x, (b->mn.y - origin.y) / dir.y, (b->mn.z - origin.z) / dir.z);
+    v3 tMax = V3((b->mx.x - origin.x) / dir.x, (b->mx.y - origin.y) / dir.y, (b->mx.z - origin.z) / dir.z);
+    v3 t1 = V3(fminf(tMin.x, tMax.x), fminf(tMin.y, tMax.y), fminf(tMin.z, tMax.z));
+    v3 t2 = V3(fmaxf(tMin.x, tMax.x), fmaxf(tMin.y, tMax.y), fmaxf(tMin.z, tMax.z));
+    *tNear = fmaxf(fmaxf(t1.x, t1.y), t1.z);
+    *tFar = fminf(fminf(t2.x, t2.y), t2.z);
+    *normal = V3((t1.x == *tNear ? 1.0f : 0.0f) * signf_glsl(-dir.x), (t1.y == *tNear ? 1.0f : 0.0f) * signf_glsl(-dir.y),
+                 (t1.z == *tNear ? 1.0f : 0.0f) * signf_glsl(-dir.z));
+}
+
+/* random.glsl:152-157 */
+static inline int inrect(v3 p, v3 c, v3 x, v3 y) {
+    float px = dot3(vsub(p, c), x), py = dot3(vsub(p, c), y);
+    return px >= 0.0f && py >= 0.0f && px < dot3(x, x) && py < dot3(y, y);
+}
+/* random.glsl:144-150 */
+static inline v4 randomRectangleAreaDirection(v3 p, v3 c, v3 x, v3 y, float rx, float ry) {
+    v3 s = vadd(vadd(c, vscale(x, rx)), vscale(y, ry)), sp = vsub(p, s);
+    float len2 = dot3(sp, sp);
+    v3 d = vscale(sp, rsq(len2));
+    v4 r = {-d.x, -d.y, -d.z, len2 / fmaxf(0.0f, dot3(d, cross3(x, y)))};
+    return r;
+}
+/* random.glsl:159-167 */
+static inline float randomRectangleAreaDirectionPDF(v3 p, v3 c, v3 x, v3 y, v3 v) {
+    v3 n = cross3(x, y);
+    float den = dot3(n, v), t = dot3(vsub(c, p), n) / den;
+    v3 s = vadd(p, vscale(v, t)), sp = vsub(p, s);
+    float len2 = dot3(sp, sp);
+    v3 d = vscale(sp, rsq(len2));
+    float flag = (den < 0.0f && t > 0.0f && inrect(s, c, x, y)) ? 1.0f : 0.0f;
+    return flag * len2 / dot3(d, n);
+}
+
+typedef struct {
+    const orc_analytic_params *p;
+    int px, py;
+} actx_t;
+
+/* trace1.cs:201-213; out-of-range table reads give 0 (the last pixels' entries for dimensions >= 8) */
+static inline uint32_t tableAt(const uint8_t *t, uint32_t n, uint32_t i) { return (t && i < n) ? t[i] : 0u; }
+static float sampleBlueNoise(const actx_t *c, uint32_t dim) {
+    const orc_analytic_params *p = c->p;
+    uint32_t xoff = orc_hash3((uint32_t)(c->py >> 7), (uint32_t)(c->px >> 7), (uint32_t)(p->frame_index >> 8));
+    uint32_t yoff = orc_hash3((uint32_t)(c->px >> 7), (uint32_t)(c->py >> 7), (uint32_t)(p->frame_index >> 8));
+    uint32_t pxox = ((uint32_t)c->px + xoff) & 127u, pxoy = ((uint32_t)c->py + yoff) & 127u;
+    uint32_t sampleIndex = (uint32_t)p->frame_index & 255u;
+    dim &= 255u;
+    uint32_t pxv = (pxox + (pxoy << 7)) << 3;
+    uint32_t ranked = sampleIndex ^ tableAt(p->ranking, 131072u, dim + pxv);
+    uint32_t value = tableAt(p->sobol, 65536u, dim + (ranked << 8));
+    value ^= tableAt(p->scramble, 131072u, (dim & 7u) + pxv);
+    return (0.5f + (float)value) / 256.0f;
+}
+
+static void randvec3_analytic(const actx_t *c, int kernel, int s, float *a, float *b, float *d) {
+    const orc_analytic_params *p = c->p;
+    float fx = (float)(c->px + s), fy = (float)(c->py + s);
+    if (kernel == 0) { /* trace.cs:95-102 */
+        *a = orc_random3(fx, fy, p->time);
+        *b = orc_random3(fx, fy, p->time + 1.1f);
+        *d = orc_random3(fx, fy, p->time + 0.3f);
+    } else if (p->use_blue_noise) { /* trace1.cs:215-229 */
+        *a = sampleBlueNoise(c, (uint32_t)(3 * s));
+        *b = sampleBlueNoise(c, (uint32_t)(3 * s + 1));
+        *d = sampleBlueNoise(c, (uint32_t)(3 * s + 2));
+    } else { /* trace1.cs:231-238 */
+        *a = orc_random3(fx, fy, p->time);
+        *b = orc_random3(fx, fy, p->time * 1.1f);
+        *d = orc_random3(fx, fy, p->time * 0.3f);
+    }
+}
+
+/* trace.cs:104-109 == trace1.cs:245-250 */
+static inline float brdfSpecularPhong(float a, v3 i, v3 o, v3 n) {
+    v3 r = reflect3(vneg(i), n);
+    return powf(fmaxf(0.0f, dot3(r, o)), a) * (a + 2.0f) / TWO_PI_F;
+}
+
+typedef struct {
+    v3 L, point0, normal0;
+    int id0;
+} apath_t;
+
+/* trace.cs:78-93 / trace1.cs:161-189: nearest box, then (trace1) the rectangle */
+static int intersectRoom(v3 origin, v3 dir, int with_rect, v3 *normal, float *near, int *bi, int *isRect) {
+    float smallest = 1E+10f;
+    int found = 0;
+    for (int i = 0; i < 11; i++) {
+        v3 n;
+        float tn, tf;
+        boxSlabs(origin, dir, &BOXES_ROOM[i], &n, &tn, &tf);
+        if (tn > 0.0f && tn < tf && tn < smallest) {
+            *near = tn; *bi = i; *isRect = 0; *normal = n; smallest = tn; found = 1;
+        }
+    }
+    if (with_rect) { /* trace1.cs:151-157,177-187 */
+        const rect_t *r = &RECT_LIGHT;
+        v3 n = cross3(r->x, r->y);
+        float den = dot3(n, dir), t = dot3(vsub(r->c, origin), n) / den;
+        if (den < 0.0f && t > 0.0f && inrect(vadd(origin, vscale(dir, t)), r->c, r->x, r->y) && t < smallest) {
+            *near = t; *bi = 0; *isRect = 1; found = 1;
+        }
+    }
+    return found;
+}
+
+/* trace.cs:138-250 */
+static void traceBoxes(const actx_t *c, v3 origin, v3 dir, apath_t *out) {
+    const orc_analytic_params *p = c->p;
+    const v3 SKY = V3(0.89f, 0.96f, 1.00f);
+    v3 att = V3(1, 1, 1);
+    out->L = V3(0, 0, 0); out->point0 = V3(0, 0, 0); out->normal0 = V3(0, 0, 0); out->id0 = -1;
+    for (int bounce = 0; bounce < 3; bounce++) {
+        v3 normal = V3(0, 0, 0);
+        float near = 0;
+        int bi = 0, isRect = 0;
+        if (!intersectRoom(origin, dir, 0, &normal, &near, &bi, &isRect)) {
+            float d = dir.y;
+            if (bounce == 0) { out->L = vmul(SKY, att); return; }
+            out->L = vscale(vmul(vscale(SKY, 4.0f), att), d);
+            return;
+        }
+        const box_t *b = &BOXES_ROOM[bi];
+        v3 point = vadd(origin, vscale(dir, near));
+        if (bounce == 0) { out->point0 = point; out->normal0 = normal; out->id0 = bi; }
+        origin = vadd(point, vscale(normal, EPSILON_F));
+        float r0, r1, r2;
+        randvec3_analytic(c, 0, bounce, &r0, &r1, &r2);
+        v4 s;
+        if (p->importance_sampled) {
+            if (r2 < p->specular_factor) {
+                v3 r = reflect3(dir, normal);
+                s = randomPhongWeightedHemispherePoint(r, p->phong_exponent, r0, r1);
+                float sp = brdfSpecularPhong(p->phong_exponent, V3(s.x, s.y, s.z), vneg(dir), normal);
+                att = vscale(att, sp);
+            } else {
+                s = randomCosineWeightedHemispherePoint(normal, r0, r1);
+                att = vmul(att, vdivs(b->col, PI_F));
+            }
+        } else {
+            s = randomHemispherePoint(normal, r0, r1);
+            float sp = brdfSpecularPhong(p->phong_exponent, V3(s.x, s.y, s.z), vneg(dir), normal);
+            v3 f = vadd(vscale(V3(sp, sp, sp), p->specular_factor), vscale(vdivs(b->col, PI_F), 1.0f - p->specular_factor));
+            att = vmul(att, f);
+        }
+        dir = V3(s.x, s.y, s.z);
+        att = vscale(att, fmaxf(0.0f, dot3(dir, normal)));
+        if (s.w > 0.0f) att = vdivs(att, s.w);
+    }
+}
+
+/* trace1.cs:271-360 */
+static void traceBoxesLight(const actx_t *c, v3 origin, v3 dir, apath_t *out) {
+    const orc_analytic_params *p = c->p;
+    v3 att = V3(1, 1, 1);
+    out->L = V3(0, 0, 0); out->point0 = V3(0, 0, 0); out->normal0 = V3(0, 0, 0); out->id0 = -1;
+    const rect_t *li = &RECT_LIGHT;
+    for (int bounce = 0; bounce < 5; bounce++) {
+        v3 normal = V3(0, 0, 0);
+        float near = 0;
+        int bi = 0, isRect = 0;
+        if (!intersectRoom(origin, dir, 1, &normal, &near, &bi, &isRect)) return;
+        v3 point = vadd(origin, vscale(dir, near));
+        if (isRect) {
+            if (bounce == 0) { out->point0 = point; out->normal0 = cross3(li->x, li->y); out->id0 = 100 + bi; }
+            out->L = vscale(att, 80.0f);
+            return;
+        }
+        v3 albedo = BOXES_ROOM[bi].col;
+        if (bounce == 0) { out->point0 = point; out->normal0 = normal; out->id0 = bi; }
+        origin = vadd(point, vscale(normal, EPSILON_F));
+        float r0, r1, r2;
+        randvec3_analytic(c, 1, bounce, &r0, &r1, &r2);
+        v4 s;
+        const float a = p->phong_exponent;
+        if (p->multiple_importance_sampled) {
+            const float wl = 0.6f, sf = p->specular_factor;
+            v3 ps = V3(wl, sf, 1.0f - sf);
+            v3 np = vdivs(ps, (ps.x + ps.y) + ps.z);
+            float cdfx = np.x, cdfy = np.x + np.y;
+            v3 pp, cc;
+            v3 r = reflect3(dir, normal);
+            if (r2 < cdfx) {
+                s = randomRectangleAreaDirection(origin, li->c, li->x, li->y, r0, r1);
+                v3 sd = V3(s.x, s.y, s.z);
+                pp = V3(s.w, randomCosineWeightedHemispherePDF(normal, sd), randomPhongWeightedHemispherePDF(r, a, sd));
+                cc = V3(np.x, np.z, np.y);
+            } else if (r2 < cdfy) {
+                s = randomPhongWeightedHemispherePoint(r, a, r0, r1);
+                v3 sd = V3(s.x, s.y, s.z);
+                pp = V3(s.w, randomCosineWeightedHemispherePDF(normal, sd),
+                        randomRectangleAreaDirectionPDF(origin, li->c, li->x, li->y, sd));
+                cc = V3(np.y, np.z, np.x);
+            } else {
+                s = randomCosineWeightedHemispherePoint(normal, r0, r1);
+                v3 sd = V3(s.x, s.y, s.z);
+                pp = V3(s.w, randomPhongWeightedHemispherePDF(r, a, sd),
+                        randomRectangleAreaDirectionPDF(origin, li->c, li->x, li->y, sd));
+                cc = V3(np.z, np.y, np.x);
+            }
+            s.w = dot3(pp, cc);
+        } else {
+            s = randomHemispherePoint(normal, r0, r1);
+        }
+        v3 sd = V3(s.x, s.y, s.z);
+        float sp = brdfSpecularPhong(a, sd, vneg(dir), normal);
+        v3 f = vadd(vscale(V3(sp, sp, sp), p->specular_factor), vscale(vdivs(albedo, PI_F), 1.0f - p->specular_factor));
+        att = vmul(att, f);
+        dir = sd;
+        att = vscale(att, fmaxf(0.0f, dot3(dir, normal)));
+        if (s.w > 0.0f) att = vdivs(att, s.w);
+    }
+}
+
+/* trace2.cs:76-146 */
+static int clipQuadToHorizon(v3 L[5]) {
+#define CLIP(a, b) vadd(vscale(L[b], -L[a].z), vscale(L[a], L[b].z)) /* -L[a].z * L[b] + L[b].z * L[a] */
+    int config = (L[0].z > 0.0f) | (L[1].z > 0.0f) << 1 | (L[2].z > 0.0f) << 2 | (L[3].z > 0.0f) << 3;
+    switch (config) {
+    case 1: L[1] = CLIP(1, 0); L[2] = CLIP(3, 0); L[3] = L[0]; return 3;
+    case 2: L[0] = CLIP(0, 1); L[2] = CLIP(2, 1); L[3] = L[0]; return 3;
+    case 3: L[2] = CLIP(2, 1); L[3] = CLIP(3, 0); L[4] = L[0]; return 4;
+    case 4: L[0] = CLIP(3, 2); L[1] = CLIP(1, 2); L[3] = L[0]; return 3;
+    case 6: L[0] = CLIP(0, 1); L[3] = CLIP(3, 2); L[4] = L[0]; return 4;
+    case 7: L[4] = CLIP(3, 0); L[3] = CLIP(3, 2); return 5;
+    case 8: L[0] = CLIP(0, 3); L[1] = CLIP(2, 3); L[2] = L[3]; L[3] = L[0]; return 3;
+    case 9: L[1] = CLIP(1, 0); L[2] = CLIP(2, 3); L[4] = L[0]; return 4;
+    case 11: L[4] = L[3]; L[3] = CLIP(2, 3); L[2] = CLIP(2, 1); return 5;
+    case 12: L[1] = CLIP(1, 2); L[0] = CLIP(0, 3); L[4] = L[0]; return 4;
+    case 13: L[4] = L[3]; L[3] = L[2]; L[2] = CLIP(1, 2); L[1] = CLIP(1, 0); return 5;
+    case 14: L[4] = CLIP(0, 3); L[0] = CLIP(0, 1); return 5;
+    case 15: L[4] = L[0]; return 4;
+    default: return 0;
+    }
+#undef CLIP
+}
+/* trace2.cs:151-158 */
+static inline float integrateEdge(v3 v1, v3 v2) {
+    float x = dot3(v1, v2), y = fabsf(x);
+    float a = 0.8543985f + (0.4965155f + 0.0145206f * y) * y;
+    float b = 3.4175940f + (4.1616724f + y) * y;
+    float v = a / b;
+    float sel = (x <= 0.0f) ? 0.5f * rsq(fmaxf(1.0f - x * x, 1E-7f)) - v : v;
+    return (v1.x * v2.y - v1.y * v2.x) * sel;
+}
+/* trace2.cs:163-184; Mt = mat3(T1,T2,N) * M with M = [[m.x,0,m.z],[0,1,0],[m.y,0,m.w]] (columns) */
+static float ltcEvaluate(v3 N, v3 V, v3 P, v4 m, const rect_t *r) {
+    v3 T1 = normalize3(vsub(V, vscale(N, dot3(V, N)))), T2 = cross3(T1, N);
+    v3 c0 = vadd(vadd(vscale(T1, m.x), vscale(T2, 0.0f)), vscale(N, m.z));
+    v3 c1 = vadd(vadd(vscale(T1, 0.0f), vscale(T2, 1.0f)), vscale(N, 0.0f));
+    v3 c2 = vadd(vadd(vscale(T1, m.y), vscale(T2, 0.0f)), vscale(N, m.w));
+    v3 L[5];
+    v3 q0 = vsub(r->c, P), q1 = vsub(vadd(r->c, r->x), P), q2 = vsub(vadd(vadd(r->c, r->x), r->y), P),
+       q3 = vsub(vadd(r->c, r->y), P);
+    L[0] = V3(dot3(q0, c0), dot3(q0, c1), dot3(q0, c2));
+    L[1] = V3(dot3(q1, c0), dot3(q1, c1), dot3(q1, c2));
+    L[2] = V3(dot3(q2, c0), dot3(q2, c1), dot3(q2, c2));
+    L[3] = V3(dot3(q3, c0), dot3(q3, c1), dot3(q3, c2));
+    L[4] = V3(0, 0, 0);
+    int n = clipQuadToHorizon(L);
+    if (n == 0) return 0.0f;
+    for (int k = 0; k < 5; k++) L[k] = normalize3(L[k]);
+    float sum = integrateEdge(L[0], L[1]) + integrateEdge(L[1], L[2]);
+    sum = sum + integrateEdge(L[2], L[3]);
+    sum = sum + (n < 4 ? 0.0f : integrateEdge(L[3], L[4]));
+    sum = sum + (n != 5 ? 0.0f : integrateEdge(L[4], L[0]));
+    return fabsf(sum);
+}
+/* texture(sampler2D, uv): 64x64 RGBA32F, GL_LINEAR, clamp-to-edge (reference src/Tracer.cpp:28-35) */
+static v4 ltcFetch(const float *lut, float u, float v) {
+    float fu = u * 64.0f - 0.5f, fv = v * 64.0f - 0.5f;
+    fu = fmaxf(fu, 0.0f); fv = fmaxf(fv, 0.0f);
+    float flu = floorf(fu), flv = floorf(fv);
+    float wu = fu - flu, wv = fv - flv;
+    int i0 = (int)flu, j0 = (int)flv;
+    if (i0 > 63) i0 = 63;
+    if (j0 > 63) j0 = 63;
+    int i1 = i0 + 1 > 63 ? 63 : i0 + 1, j1 = j0 + 1 > 63 ? 63 : j0 + 1;
+    v4 o;
+    float *po = &o.x;
+    for (int k = 0; k < 4; k++) {
+        float a = lut[4 * (j0 * 64 + i0) + k], b = lut[4 * (j0 * 64 + i1) + k];
+        float cc = lut[4 * (j1 * 64 + i0) + k], d = lut[4 * (j1 * 64 + i1) + k];
+        float top = a + wu * (b - a), bot = cc + wu * (d - cc);
+        po[k] = top + wv * (bot - top);
+    }
+    return o;
+}
+/* trace2.cs:207-278 */
+static void traceLtc(const actx_t *c, v3 origin, v3 dir, apath_t *out) {
+    const orc_analytic_params *p = c->p;
+    out->L = V3(0, 0, 0); out->point0 = V3(0, 0, 0); out->normal0 = V3(0, 0, 0); out->id0 = -1;
+    float smallest = 1E+10f, near = 0;
+    int found = 0, idx = 0, isRect = 0;
+    v3 normal = V3(0, 0, 0);
+    for (int i = 0; i < 5; i++) {
+        v3 n;
+        float tn, tf;
+        boxSlabs(origin, dir, &BOXES_LTC[i], &n, &tn, &tf);
+        if (tf >= 0.0f && tn < tf && tn < smallest) { near = tn; idx = i; isRect = 0; normal = n; smallest = tn; found = 1; }
+    }
+    for (int i = 0; i < 16; i++) { /* trace2.cs:189-194 */
+        const rect_t *r = &RECTS_LTC[i];
+        v3 n = cross3(r->x, r->y);
+        float den = dot3(n, dir), t = dot3(vsub(r->c, origin), n) / den;
+        if (den != 0.0f && t > 0.0f && inrect(vadd(origin, vscale(dir, t)), r->c, r->x, r->y) && t < smallest) {
+            near = t; idx = i; isRect = 1; smallest = t; found = 1;
+        }
+    }
+    if (!found) return;
+    v3 point = vadd(origin, vscale(dir, near));
+    out->point0 = point;
+    if (isRect) {
+        out->normal0 = cross3(RECTS_LTC[idx].x, RECTS_LTC[idx].y);
+        out->id0 = 100 + idx;
+        out->L = V3(1, 1, 1);
+        return;
+    }
+    out->normal0 = normal;
+    out->id0 = idx;
+    v3 albedo = BOXES_LTC[idx].col;
+    float uvx = p->roughness * 0.984375f + 0.0078125f;
+    float uvy = sqrtf(1.0f - fminf(1.0f, fmaxf(0.0f, dot3(normal, vneg(dir))))) * 0.984375f + 0.0078125f;
+    v4 m = ltcFetch(p->ltc1, uvx, uvy), f = ltcFetch(p->ltc2, uvx, uvy);
+    float col = 0.0f;
+    for (int i = 0; i < 16; i++) col += ltcEvaluate(normal, vneg(dir), point, m, &RECTS_LTC[i]) * f.x;
+    out->L = vscale(vscale(albedo, col), 6.0f);
+}
+
+void orc_trace_analytic(int32_t kernel, const orc_analytic_params *p, float *color, int8_t *normal, uint16_t *pos,
+                        int32_t *objid) {
+    const int W = p->width, H = p->height;
+    int x0 = p->x0, y0 = p->y0, x1 = p->x1, y1 = p->y1;
+    if (x0 == 0 && y0 == 0 && x1 == 0 && y1 == 0) { x1 = W; y1 = H; }
+    const v3 eye = ld3(p->eye), r00 = ld3(p->ray00), r01 = ld3(p->ray01), r10 = ld3(p->ray10), r11 = ld3(p->ray11);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = y0; y < y1; y++) {
+        for (int x = x0; x < x1; x++) {
+            actx_t c = {p, x, y};
+            float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
+            v3 dir = normalize3(mix3(mix3(r00, r01, pyf), mix3(r10, r11, pyf), pxf));
+            apath_t path;
+            if (kernel == 0) traceBoxes(&c, eye, dir, &path);
+            else if (kernel == 1) traceBoxesLight(&c, eye, dir, &path);
+            else traceLtc(&c, eye, dir, &path);
+            const size_t i = (size_t)y * W + x;
+            v3 fin = path.L;
+            if (kernel != 2) { /* trace.cs:264-268, trace1.cs:374-378; trace2.cs:289-290 stores the colour as is */
+                v3 old = V3(0, 0, 0);
+                if (p->blend_factor > 0.0f) old = V3(color[4 * i], color[4 * i + 1], color[4 * i + 2]);
+                fin = mix3(path.L, old, p->blend_factor);
+            }
+            color[4 * i] = fin.x; color[4 * i + 1] = fin.y; color[4 * i + 2] = fin.z; color[4 * i + 3] = 1.0f;
+            if (normal) {
+                normal[4 * i] = orc_f32_to_snorm8(path.normal0.x);
+                normal[4 * i + 1] = orc_f32_to_snorm8(path.normal0.y);
+                normal[4 * i + 2] = orc_f32_to_snorm8(path.normal0.z);
+                normal[4 * i + 3] = 0;
+            }
+            if (pos) {
+                pos[4 * i] = orc_f32_to_f16_rtz(path.point0.x);
+                pos[4 * i + 1] = orc_f32_to_f16_rtz(path.point0.y);
+                pos[4 * i + 2] = orc_f32_to_f16_rtz(path.point0.z);
+                pos[4 * i + 3] = orc_f32_to_f16_rtz(1.0f);
+            }
+            if (objid) objid[i] = path.id0;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ atrous.fs */
 static inline v4 fetchColor(const void *img, int is_f32, int W, int H, int x, int y) {
     v4 r = {0, 0, 0, 0};

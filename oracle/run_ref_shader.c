@@ -101,7 +101,7 @@ static void loadGL(void) {
 }
 
 /* ---------------------------------------------------------------- job file */
-#define MAXKV 64
+#define MAXKV 96
 static char *jobKeys[MAXKV], *jobVals[MAXKV];
 static int jobN;
 
@@ -300,20 +300,57 @@ int main(int argc, char **argv) {
 
     /* ---------------- trace program (skipped when spp == 0: filter-only job) */
     if (spp > 0) {
-        const char *files[] = {"src/shaders/trace3.cs", "src/shaders/geometry.glsl", "src/shaders/random.glsl",
-                               "src/shaders/qtablehelper.glsl"}; /* reference src/Tracer.cpp:14 */
-        GLuint sh[4];
-        for (int i = 0; i < 4; i++) {
-            snprintf(path, sizeof path, "%s/%s", refDir, files[i]);
-            char *src = readFile(path, NULL);
-            if (!src) { fprintf(stderr, "reference oracle unavailable: cannot read %s\n", path); return GLH_UNAVAILABLE; }
-            if (i == 0 && instrument) {
-                src = replaceOnce(src, NULL, "uniform image2D posbuffer;",
-                                  "uniform image2D posbuffer;\n"
+        /* shader=trace3 is the live kernel (reference src/Tracer.cpp:14); trace / trace1 / trace2 are the
+         * reference's other kernels, each linked with random.glsl for the functions they declare. */
+        const char *shader = jobStr("shader", "trace3");
+        const char *files3[] = {"src/shaders/trace3.cs", "src/shaders/geometry.glsl", "src/shaders/random.glsl",
+                                "src/shaders/qtablehelper.glsl"};
+        const char *filesBox[] = {"src/shaders/trace.cs", "src/shaders/random.glsl"};
+        const char *filesBn[] = {"src/shaders/trace1.cs", "src/shaders/random.glsl"};
+        const char *filesLtc[] = {"src/shaders/trace2.cs", "src/shaders/random.glsl"};
+        const char **files = files3;
+        int nfiles = 4, variant = 3;
+        if (!strcmp(shader, "trace")) { files = filesBox; nfiles = 2; variant = 0; }
+        else if (!strcmp(shader, "trace1")) { files = filesBn; nfiles = 2; variant = 1; }
+        else if (!strcmp(shader, "trace2")) { files = filesLtc; nfiles = 2; variant = 2; }
+        else if (strcmp(shader, "trace3")) { fprintf(stderr, "unknown shader=%s\n", shader); return 2; }
+        const char *extraImages = "uniform image2D posbuffer;\n"
                                   "layout(binding = 3, r32i) uniform iimage2D o_tridx;\n"
                                   "layout(binding = 4, r32i) uniform iimage2D o_visits;\n"
                                   "layout(binding = 5, rgba32i) uniform iimage2D o_stats;\n"
-                                  "int g_iter = 0; int g_rays = 0; int g_visits = 0; int g_tests = 0;\n");
+                                  "int g_iter = 0; int g_rays = 0; int g_visits = 0; int g_tests = 0;\n";
+        GLuint sh[4];
+        for (int i = 0; i < nfiles; i++) {
+            snprintf(path, sizeof path, "%s/%s", refDir, files[i]);
+            char *src = readFile(path, NULL);
+            if (!src) { fprintf(stderr, "reference oracle unavailable: cannot read %s\n", path); return GLH_UNAVAILABLE; }
+            /* Load-time portability patches; arithmetic untouched, never written back. */
+            if (i == 0 && variant == 1) {
+                /* trace1.cs:83-93 declares uint8_t[] buffers (GL_NV_gpu_shader5 / EXT_shader_8bit_storage, absent on
+                 * llvmpipe): same bytes read through uint[] words, little-endian byte extraction. */
+                src = replaceOnce(src, NULL, "uint8_t[] sobols;", "uint[] sobols_w;");
+                src = replaceOnce(src, NULL, "uint8_t[] scrambles;", "uint[] scrambles_w;");
+                src = replaceOnce(src, NULL, "uint8_t[] rankings;",
+                                  "uint[] rankings_w;\n};\n"
+                                  "uint byteOf(uint w, uint i) { return (w >> ((i & 3u) * 8u)) & 255u; }\n"
+                                  "uint sobolsAt(uint i) { return byteOf(sobols_w[i >> 2u], i); }\n"
+                                  "uint scramblesAt(uint i) { return byteOf(scrambles_w[i >> 2u], i); }\n"
+                                  "uint rankingsAt(uint i) { return byteOf(rankings_w[i >> 2u], i); }\n"
+                                  "struct unused_tail_ { int x;");
+                src = replaceOnce(src, "float sampleBlueNoise(", "rankings[sampleDimension + pxv]",
+                                  "rankingsAt(sampleDimension + pxv)");
+                src = replaceOnce(src, "float sampleBlueNoise(", "sobols[sampleDimension + (rankedSampleIndex << 8u)]",
+                                  "sobolsAt(sampleDimension + (rankedSampleIndex << 8u))");
+                src = replaceOnce(src, "float sampleBlueNoise(", "scrambles[(sampleDimension & 7u) + pxv]",
+                                  "scramblesAt((sampleDimension & 7u) + pxv)");
+            }
+            if (i == 0 && variant == 2) {
+                /* texture2D() is not in core 4.30 (trace2.cs:266-267) */
+                src = replaceOnce(src, NULL, "texture2D(ltc_mat, uv)", "texture(ltc_mat, uv)");
+                src = replaceOnce(src, NULL, "texture2D(ltc_mag, uv)", "texture(ltc_mag, uv)");
+            }
+            if (i == 0 && instrument && variant == 3) {
+                src = replaceOnce(src, NULL, "uniform image2D posbuffer;", extraImages);
                 src = replaceOnce(src, "int intersectTriangles(", "const triangle tri = triangles[i];",
                                   "const triangle tri = triangles[i]; g_tests++;");
                 src = replaceOnce(src, "void intersectGeometry(", "      SI.tridx = -1;",
@@ -329,10 +366,33 @@ int main(int argc, char **argv) {
                                   "imageStore(framebuffer, pix, vec4(finalColor, 1.0));\n"
                                   "  imageStore(o_stats, pix, ivec4(g_rays, g_visits, g_tests, floatBitsToInt(rand_seeds[-1 - (pix.x % 3)])));");
             }
+            if (i == 0 && instrument && variant != 3) {
+                /* primary-hit object id: box index, 100 + rectangle index, -1 for a miss; o_visits = number of
+                 * bounces that found a hit is not recorded (the analytic kernels have no traversal). */
+                const char *anchor = "vec3 trace(vec3 origin, vec3 dir) {";
+                src = replaceOnce(src, NULL, "uniform image2D posbuffer;", extraImages);
+                src = replaceOnce(src, anchor, "write(vec3(0.0), vec3(0.0));",
+                                  "{ write(vec3(0.0), vec3(0.0)); imageStore(o_tridx, px, ivec4(-1)); }");
+                if (variant == 0) {
+                    src = replaceOnce(src, anchor, "write(point, normal);",
+                                      "{ write(point, normal); imageStore(o_tridx, px, ivec4(hinfo.bi)); }");
+                } else if (variant == 1) {
+                    src = replaceOnce(src, anchor, "write(point, normalForRectangle(point, r));",
+                                      "{ write(point, normalForRectangle(point, r)); imageStore(o_tridx, px, ivec4(100 + hinfo.bi)); }");
+                    src = replaceOnce(src, anchor, "write(point, normal);",
+                                      "{ write(point, normal); imageStore(o_tridx, px, ivec4(hinfo.bi)); }");
+                } else {
+                    src = replaceOnce(src, anchor, "write(point, normalForRectangle(point, r));",
+                                      "{ write(point, normalForRectangle(point, r)); imageStore(o_tridx, px, ivec4(100 + hinfo.i)); }");
+                    src = replaceOnce(src, anchor, "write(point, normal);",
+                                      "{ write(point, normal); imageStore(o_tridx, px, ivec4(hinfo.i)); }");
+                }
+            }
+            if (jobInt("dump_source", 0) && i == 0) fprintf(stderr, "%s\n", src);
             sh[i] = compile(GL_COMPUTE_SHADER, src, files[i]);
             free(src);
         }
-        GLuint prog = linkProgram(sh, 4);
+        GLuint prog = linkProgram(sh, nfiles);
         GLint wg[3];
         p_glGetProgramiv(prog, GL_COMPUTE_WORK_GROUP_SIZE, wg);
         printf("work_group %d %d %d\n", wg[0], wg[1], wg[2]);
@@ -344,6 +404,30 @@ int main(int argc, char **argv) {
         }
         ssbo(3, "nodes"); ssbo(4, "tris"); ssbo(5, "mtls"); ssbo(6, "emitters");
         ssbo(7, "vnormals"); ssbo(8, "vcentres"); ssbo(9, "qtable"); ssbo(10, "qvisits");
+        if (variant == 1) { /* reference src/Tracer.cpp:50-90,169-171 */
+            ssbo(0, "sobol"); ssbo(1, "scramble"); ssbo(2, "ranking");
+        }
+        if (variant == 2) { /* reference src/Tracer.cpp:23-48; units from trace2.cs:12-13 */
+            const char *keys[2] = {"ltc1", "ltc2"};
+            for (int k = 0; k < 2; k++) {
+                size_t n;
+                const char *lp = jobStr(keys[k], NULL);
+                char *b = lp ? readFile(lp, &n) : NULL;
+                if (!b || n != 64 * 64 * 16) { fprintf(stderr, "bad %s\n", keys[k]); return 2; }
+                GLuint t;
+                p_glGenTextures(1, &t);
+                p_glActiveTexture(GL_TEXTURE0 + k);
+                p_glBindTexture(GL_TEXTURE_2D, t);
+                p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_S, GL_CLAMP_TO_EDGE);
+                p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_CLAMP_TO_EDGE);
+                p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MIN_FILTER, GL_LINEAR);
+                p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_MAG_FILTER, GL_LINEAR);
+                p_glTexStorage2D(GL_TEXTURE_2D, 1, GL_RGBA32F, 64, 64);
+                p_glTexSubImage2D(GL_TEXTURE_2D, 0, 0, 0, 64, 64, GL_RGBA, GL_FLOAT, b);
+                free(b);
+            }
+            p_glActiveTexture(GL_TEXTURE2);
+        }
 
         float eye[3], r00[3], r01[3], r10[3], r11[3];
         jobVec3("eye", eye); jobVec3("ray00", r00); jobVec3("ray01", r01); jobVec3("ray10", r10); jobVec3("ray11", r11);
@@ -366,6 +450,14 @@ int main(int argc, char **argv) {
                 p_glUniform1i(p_glGetUniformLocation(prog, "maxPhi"), 10);
                 p_glUniform1i(p_glGetUniformLocation(prog, "maxTheta"), 10);
                 p_glUniform1i(p_glGetUniformLocation(prog, "maxBounces"), jobInt("max_bounces", 5));
+                /* uniforms of the other kernels (commented-out setters, reference src/Tracer.cpp:147-153); a
+                 * location of -1 is ignored by GL */
+                p_glUniform1f(p_glGetUniformLocation(prog, "phongExponent"), jobFloat("phong_exponent", 128.0f));
+                p_glUniform1f(p_glGetUniformLocation(prog, "specularFactor"), jobFloat("specular_factor", 0.2f));
+                p_glUniform1f(p_glGetUniformLocation(prog, "roughness"), jobFloat("roughness", 0.5f));
+                p_glUniform1i(p_glGetUniformLocation(prog, "multipleImportanceSampled"), jobInt("mis", 1));
+                p_glUniform1i(p_glGetUniformLocation(prog, "useBlueNoise"), jobInt("use_blue_noise", 1));
+                p_glUniform1i(p_glGetUniformLocation(prog, "frameIndex"), frame);
                 p_glBindImageTexture(0, colorTex, 0, GL_FALSE, 0, GL_READ_WRITE, GL_RGBA32F);
                 p_glBindImageTexture(1, normTex, 0, GL_FALSE, 0, GL_WRITE_ONLY, GL_RGBA8_SNORM);
                 p_glBindImageTexture(2, posTex, 0, GL_FALSE, 0, GL_WRITE_ONLY, GL_RGBA16F);

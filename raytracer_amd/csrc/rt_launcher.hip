@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "rt_device.h"
+#include "analytic.h"
 #include "wavefront.h"
 
 hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace_params &p, const rt_rect &tile,
@@ -559,6 +560,50 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
                                          c->profile ? c : nullptr);
         span.end();
         if (e != hipSuccess) return hipFail(c, e, "wavefront launch");
+        return RT_OK;
+    }
+    case RT_KERNEL_TRACE: case RT_KERNEL_TRACE1: case RT_KERNEL_TRACE2: {
+        // The analytic-scene kernels: no scene buffers; trace1 reads the blue-noise tables when useBlueNoise is
+        // set, trace2 the two LTC look-up tables (reference src/Tracer.cpp:23-90).
+        if (p->kernel == RT_KERNEL_TRACE1 && p->useBlueNoise &&
+            (!c->tables[RT_TABLE_SOBOL].p || !c->tables[RT_TABLE_SCRAMBLE].p || !c->tables[RT_TABLE_RANKING].p))
+            return fail(c, RT_ESTATE, "rt_trace: trace1 with useBlueNoise needs the sobol, scramble and ranking tables (rt_set_table)");
+        if (p->kernel == RT_KERNEL_TRACE2 && (!c->tables[RT_TABLE_LTC1].p || !c->tables[RT_TABLE_LTC2].p))
+            return fail(c, RT_ESTATE, "rt_trace: trace2 needs the ltc1 and ltc2 tables (rt_set_table)");
+        RtScene sc;
+        RtImages img;
+        fillScene(c, sc, img);
+        AnalyticParams ap;
+        std::memset(&ap, 0, sizeof ap);
+        std::memcpy(ap.eye, p->eye, sizeof ap.eye);
+        std::memcpy(ap.ray00, p->ray00, sizeof ap.ray00);
+        std::memcpy(ap.ray01, p->ray01, sizeof ap.ray01);
+        std::memcpy(ap.ray10, p->ray10, sizeof ap.ray10);
+        std::memcpy(ap.ray11, p->ray11, sizeof ap.ray11);
+        ap.importanceSampled = p->importanceSampled;
+        ap.multipleImportanceSampled = p->multipleImportanceSampled;
+        ap.useBlueNoise = p->useBlueNoise;
+        ap.phongExponent = p->phongExponent;
+        ap.specularFactor = p->specularFactor;
+        ap.roughness = p->roughness;
+        ap.flags = p->flags;
+        ap.batch = n;
+        for (int k = 0; k < n; ++k) {
+            ap.s[k].time = params[k].time;
+            ap.s[k].blendFactor = params[k].blendFactor;
+            ap.s[k].frameIndex = params[k].frameIndex;
+        }
+        AnalyticTables tb;
+        tb.sobol = (const uint8_t *)c->tables[RT_TABLE_SOBOL].p;
+        tb.scramble = (const uint8_t *)c->tables[RT_TABLE_SCRAMBLE].p;
+        tb.ranking = (const uint8_t *)c->tables[RT_TABLE_RANKING].p;
+        tb.ltc1 = (const float4 *)c->tables[RT_TABLE_LTC1].p;
+        tb.ltc2 = (const float4 *)c->tables[RT_TABLE_LTC2].p;
+        SpanGuard span(c, TK_TRACE), span2(c, RT_TIME_PER_PIXEL);
+        hipError_t e = rtLaunchAnalytic(p->kernel, img, ap, tb, r, (RtCountersDev *)c->counters.p, c->stream);
+        span2.end();
+        span.end();
+        if (e != hipSuccess) return hipFail(c, e, "analytic kernel launch");
         return RT_OK;
     }
     default:

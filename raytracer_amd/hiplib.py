@@ -119,8 +119,10 @@ class RtError(RuntimeError):
 
 
 def make_params(rays, eye, time, blend_factor, max_bounces, num_emitters, flags=0, kernel=KERNEL_TRACE3,
-                max_follows=1000, oob="llvmpipe"):
-    """Fill rt_trace_params the way Tracer::trace does (reference src/Tracer.cpp:139-161)."""
+                max_follows=1000, oob="llvmpipe", importance=1, mis=1, use_blue_noise=1, frame_index=0,
+                phong_exponent=128.0, specular_factor=0.2, roughness=0.5):
+    """Fill rt_trace_params the way Tracer::trace does (reference src/Tracer.cpp:139-161); the defaults of the
+    trace / trace1 / trace2 uniforms are the values of its commented-out setters (:147-153)."""
     p = TraceParams()
     p.size = ctypes.sizeof(TraceParams)
     p.kernel = kernel
@@ -130,7 +132,9 @@ def make_params(rays, eye, time, blend_factor, max_bounces, num_emitters, flags=
                                                       rays[3].tolist())
     p.time = float(time)
     p.blendFactor = float(blend_factor)
-    p.importanceSampled = 1
+    p.importanceSampled = int(importance)
+    p.multipleImportanceSampled, p.useBlueNoise, p.frameIndex = int(mis), int(use_blue_noise), int(frame_index)
+    p.phongExponent, p.specularFactor, p.roughness = phong_exponent, specular_factor, roughness
     p.numPoints, p.maxPhi, p.maxTheta = 100, 10, 10
     p.numEmitters = num_emitters
     p.maxBounces = max_bounces
@@ -171,6 +175,12 @@ class Context:
             if buffers[slot] or slot <= 6:
                 self.upload(slot, buffers[slot])
 
+    def set_tables(self, tables):
+        """tables: {"sobol" | "scramble" | "ranking" | "ltc1" | "ltc2": bytes} (the reference's res/*.data contents)."""
+        ids = dict(sobol=TABLE_SOBOL, scramble=TABLE_SCRAMBLE, ranking=TABLE_RANKING, ltc1=TABLE_LTC1, ltc2=TABLE_LTC2)
+        for name, data in tables.items():
+            self.set_table(ids[name], data)
+
     def set_table(self, table, data):
         data = bytes(data)
         self._check(lib().rt_set_table(self._h, table, data, len(data)), f"rt_set_table({table})")
@@ -197,16 +207,19 @@ class Context:
         self._check(lib().rt_trace_batch(self._h, arr, len(params_list), self._rect(rect)), "rt_trace_batch")
 
     def trace_samples(self, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.0625, max_bounces=5, flags=0,
-                      rect=None, num_emitters=None, oob="llvmpipe", max_follows=1000, batch=MAX_BATCH):
-        """spp dispatches with time_k = time0 + dtime*k and blendFactor_k = k/(k+1), issued in groups of
-        up to `batch` concurrent samples (rt_trace_batch; batch=1 issues one rt_trace per sample)."""
+                      rect=None, num_emitters=None, oob="llvmpipe", max_follows=1000, batch=MAX_BATCH,
+                      kernel=KERNEL_TRACE3, **uniforms):
+        """spp dispatches with time_k = time0 + dtime*k, blendFactor_k = k/(k+1) and frameIndex_k = k, issued in
+        groups of up to `batch` concurrent samples (rt_trace_batch; batch=1 issues one rt_trace per sample).
+        `uniforms`: importance, mis, use_blue_noise, phong_exponent, specular_factor, roughness."""
         ne = self.num_emitters if num_emitters is None else num_emitters
         plist = []
         for k in range(spp):
             frame = frame0 + k
             t = np.float32(time0) + np.float32(dtime) * np.float32(frame)
             bf = np.float32(frame) / (np.float32(frame) + np.float32(1.0))
-            plist.append(make_params(rays, eye, t, bf, max_bounces, ne, flags, max_follows=max_follows, oob=oob))
+            plist.append(make_params(rays, eye, t, bf, max_bounces, ne, flags, kernel=kernel, max_follows=max_follows,
+                                     oob=oob, frame_index=frame, **uniforms))
         if batch <= 1:
             for p in plist:
                 self.trace(p, rect)

@@ -1,7 +1,9 @@
 // main.cpp — headless counterpart of the reference's window loop (reference src/main.cpp:6-138):
 // same objects built in the same order, `frames` iterations of trace (+ filter), then PNGs.
 //   rt_headless scene.obj [--size WxH] [--frames N] [--bounces B] [--filter ITERS] [--exposure E]
-//               [--auto-camera] [--light] [--out PREFIX] [--res DIR]
+//               [--auto-camera] [--light] [--out PREFIX] [--res DIR] [--kernel trace3|trace|trace1|trace2]
+// --kernel selects one of the reference's other kernels (its analytic box scenes; the obj file is still loaded,
+// as the reference's main does, but not traced); trace1 / trace2 read their tables from --res (default "res").
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -21,7 +23,7 @@ int main(int argc, char **argv) {
     int WIDTH = 512, HEIGHT = 512, frames = 4, bounces = 5, filterIters = 0;
     float exposure = 1.0f;
     bool autoCamera = false, light = false;
-    std::string out = "frame";
+    std::string out = "frame", res = "res", kernel = "trace3";
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -33,6 +35,8 @@ int main(int argc, char **argv) {
         else if (a == "--auto-camera") autoCamera = true;
         else if (a == "--light") light = true;
         else if (a == "--out") out = next();
+        else if (a == "--res") res = next();
+        else if (a == "--kernel") kernel = next();
         else { std::cerr << "unknown option " << a << std::endl; return -1; }
     }
     try {
@@ -63,7 +67,18 @@ int main(int argc, char **argv) {
         }
         Camera camera(eye, lookAt, rtm::vec3(0.0f, 1.0f, 0.0f), 60.0f, (float)WIDTH, (float)HEIGHT, 1.0f, 2.0f);
 
-        Tracer tracer(&camera, &framebuffer, &bvh, &qt);
+        const std::string main_cs = "src/shaders/" + kernel + ".cs";
+        if (kernel != "trace3" && kernel != "trace" && kernel != "trace1" && kernel != "trace2") {
+            std::cerr << "unknown kernel " << kernel << std::endl;
+            return -1;
+        }
+        Tracer tracer = kernel == "trace3"
+                            ? Tracer(&camera, &framebuffer, &bvh, &qt)
+                            : Tracer(&camera, &framebuffer, &bvh, &qt,
+                                     std::vector<const char *>{main_cs.c_str(), "src/shaders/random.glsl"});
+        tracer.resourceDir = res;
+        if (kernel == "trace1") tracer.genBlueNoiseBuffers();
+        if (kernel == "trace2") tracer.genLtcData();
         tracer.maxBounces = bounces;
         filter.iterations = filterIters;
         rtCheck(rtApi().profile(rtCurrentContext(), 1), "rt_profile");

@@ -124,8 +124,12 @@ void FrameBuffer::saveTonemapped(std::string path, unsigned image, float exposur
 
 // ---------------------------------------------------------------------------------------
 Tracer::Tracer(Camera *camera, FrameBuffer *fbo, BVHContainer *bvh, QTable *qt)
-    : compute(std::vector<const char *>{"src/shaders/trace3.cs", "src/shaders/geometry.glsl",
-                                        "src/shaders/random.glsl", "src/shaders/qtablehelper.glsl"}),
+    : Tracer(camera, fbo, bvh, qt,
+             std::vector<const char *>{"src/shaders/trace3.cs", "src/shaders/geometry.glsl", "src/shaders/random.glsl",
+                                       "src/shaders/qtablehelper.glsl"}) {}
+
+Tracer::Tracer(Camera *camera, FrameBuffer *fbo, BVHContainer *bvh, QTable *qt, std::vector<const char *> shaderPaths)
+    : compute(shaderPaths),
       camera(camera), fbo(fbo), bvh(bvh), qt(qt), importanceSampled(true), useBlueNoise(true),
       accumulateSamples(true), maxAccumulateSamples(64), maxBounces(5),
       timeOverride(std::numeric_limits<float>::quiet_NaN()) {
@@ -135,6 +139,7 @@ Tracer::Tracer(Camera *camera, FrameBuffer *fbo, BVHContainer *bvh, QTable *qt)
     const RtApi &api = rtApi();
     rt_ctx *ctx = rtCurrentContext();
     auto up = [&](unsigned slot, const void *p, size_t n) { rtCheck(api.upload(ctx, (int)slot, p, n), "rt_upload"); };
+    if (!bvh) return; // analytic kernels
     up(bvh->nodesSsbo, bvh->nodesBuffer.data(), bvh->nodesBuffer.size() * sizeof(GPUNode));
     up(bvh->trianglesSsbo, bvh->trianglesBuffer.data(), bvh->trianglesBuffer.size() * sizeof(GPUTriangle));
     up(bvh->materialsSsbo, bvh->mtlBuffer.data(), bvh->mtlBuffer.size() * sizeof(GPUMaterial));
@@ -206,12 +211,16 @@ void Tracer::trace(int frameNumber) { // Tracer.cpp:132-198
     compute.setFloat("blendFactor", (float)frameNumber / (frameNumber + 1.0f));
     compute.setInt("importanceSampled", int(importanceSampled));
     compute.setInt("numPoints", MAX_POINTS);
-    compute.setInt("numEmitters", (int)bvh->emitters.size());
+    compute.setInt("numEmitters", bvh ? (int)bvh->emitters.size() : 0);
     compute.setInt("maxPhi", MAX_PHI);
     compute.setInt("maxTheta", MAX_THETA);
     compute.setInt("maxBounces", maxBounces);
     compute.setInt("useBlueNoise", int(useBlueNoise));
     compute.setInt("frameIndex", frameNumber);
+    compute.setInt("multipleImportanceSampled", int(importanceSampled));
+    compute.setFloat("phongExponent", phongExponent);
+    compute.setFloat("specularFactor", specularFactor);
+    compute.setFloat("roughness", roughness);
     const rt_trace_params p = compute.params();
     // image / buffer bindings of Tracer.cpp:165-180 are implicit in the context; the dispatch:
     rtCheck(rtApi().trace(rtCurrentContext(), &p, nullptr), "rt_trace");

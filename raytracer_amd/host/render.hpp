@@ -88,6 +88,10 @@ class Tracer {
 
 public:
     Tracer(Camera *camera, FrameBuffer *fbo, BVHContainer *bvh, QTable *qt);
+    // Not in the reference, where the shader list is a literal in the constructor (Tracer.cpp:14): the same
+    // constructor with the list spelt out, e.g. {"src/shaders/trace1.cs", "src/shaders/random.glsl"}.  The
+    // analytic kernels need no scene: bvh / qt may be null for them.
+    Tracer(Camera *camera, FrameBuffer *fbo, BVHContainer *bvh, QTable *qt, std::vector<const char *> shaderPaths);
     void genBlueNoiseBuffers();
     void genBlueNoiseTexes();
     void genLtcData();
@@ -103,6 +107,8 @@ public:
     // Not in the reference: the `time` uniform is wall-clock seconds there (Tracer.cpp:136-137,145);
     // a headless, reproducible run pins it per frame.  NaN = use the wall clock.
     float timeOverride;
+    // uniforms of trace.cs / trace1.cs / trace2.cs whose setters are commented out in Tracer.cpp:147-152
+    float phongExponent = 128.0f, specularFactor = 0.2f, roughness = 0.5f;
     std::string resourceDir = "res"; // where the sample tables / LUTs are read from
     rt_counters counters();
 };

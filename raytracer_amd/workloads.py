@@ -34,3 +34,25 @@ class Workload:
     @property
     def num_emitters(self):
         return self.info.num_emitters
+
+
+# ---------------------------------------------------------------------------------------------
+# The analytic-scene kernels (reference trace.cs / trace1.cs / trace2.cs) have no scene buffers; their
+# inputs are the camera and, for trace1 / trace2, the reference's sample / look-up tables.
+ANALYTIC_CAMERAS = {
+    "reference": dict(hostlib.REFERENCE_CAMERA),     # reference src/main.cpp:42-51: looks up, half the frame is sky
+    "table": dict(eye=(2.5, 3.0, 4.0), look_at=(0.0, 1.0, 0.0), up=(0.0, 1.0, 0.0), fov=60.0),  # sees table + pillar
+    "light": dict(eye=(0.5, 1.5, -2.0), look_at=(0.0, 0.3, 3.0), up=(0.0, 1.0, 0.0), fov=60.0),  # faces trace1's light
+}
+TABLE_FILES = dict(sobol="sobol_256_256_4spp.data", scramble="scramble_128_128_8_4spp.data",
+                   ranking="ranking_128_128_8_4spp.data", ltc1="ltc1.data", ltc2="ltc2.data")
+
+
+def analytic_tables():
+    """The table files Tracer::genBlueNoiseBuffers / genLtcData load (reference src/Tracer.cpp:23-90)."""
+    return {k: assets.read(f) for k, f in TABLE_FILES.items()}
+
+
+def analytic_camera(name, width, height):
+    cam = ANALYTIC_CAMERAS[name]
+    return hostlib.camera_rays(width=width, height=height, **cam), np.array(cam["eye"], np.float32)

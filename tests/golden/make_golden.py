@@ -12,7 +12,9 @@ Runs only in the build container (needs /root/reference and Mesa llvmpipe; `make
     (oracle/_ref/ref_glm_camera).
 The fixtures are data (inputs + expected outputs); no reference source text is stored.
 
-usage: python tests/golden/make_golden.py [--only trace|ids|filter|kat|semantics|camera]
+  * analytic_*.npz    : the reference's trace.cs / trace1.cs / trace2.cs on llvmpipe (trace1 / trace2 with the
+    load-time portability patches listed in oracle/run_ref_shader.c).
+usage: python tests/golden/make_golden.py [--only trace|ids|filter|kat|semantics|camera|analytic]
 """
 import argparse
 import hashlib
@@ -45,6 +47,21 @@ TRACE_CASES = [
 ]
 # full-size primary-hit ID / visit-count frames of the BASELINE.json configurations
 ID_CASES = [("teapot", 640, 480), ("suzanne", 1920, 1080), ("scene", 1920, 1080), ("room", 1920, 1080)]
+# (kernel, camera, width, height, spp, uniforms) for the analytic-scene kernels trace.cs / trace1.cs / trace2.cs
+ANALYTIC_CASES = [
+    ("trace", "reference", 160, 120, 2, {}),
+    ("trace", "table", 160, 120, 3, dict(importance=0)),
+    ("trace", "table", 128, 96, 2, dict(phong_exponent=32.0, specular_factor=0.5)),
+    ("trace1", "reference", 160, 120, 2, {}),
+    ("trace1", "table", 160, 120, 3, {}),
+    ("trace1", "table", 128, 96, 2, dict(mis=0)),
+    ("trace1", "table", 128, 96, 2, dict(use_blue_noise=0)),
+    ("trace1", "table", 256, 256, 1, {}),   # spans 128-pixel blue-noise tiles, incl. their out-of-range table reads
+    ("trace1", "light", 128, 96, 2, {}),
+    ("trace2", "reference", 160, 120, 1, {}),
+    ("trace2", "table", 160, 120, 1, {}),
+    ("trace2", "table", 128, 96, 1, dict(roughness=0.13)),
+]
 FILTER_CASES = [("room", 96, 64, 2, 5, 5), ("scene", 96, 54, 4, 5, 5), ("suzanne", 96, 54, 1, 1, 2)]
 
 
@@ -88,6 +105,23 @@ def gen_ids():
         np.savez_compressed(path, tridx=tr.astype(np.int16), visits=vi.astype(np.int16), rays=wl.rays, eye=wl.eye,
                             meta=json.dumps(meta))
         print("wrote", path, os.path.getsize(path), meta["hit_pixels"], meta["trace_ms"])
+
+
+def analytic_name(kernel, cam, w, h, spp, uni):
+    tag = "".join(f"_{k}{v:g}" for k, v in sorted(uni.items()))
+    return f"analytic_{kernel}_{cam}_{w}x{h}_{spp}spp{tag}.npz"
+
+
+def gen_analytic():
+    tables = workloads.analytic_tables()
+    for kernel, cam, w, h, spp, uni in ANALYTIC_CASES:
+        rays, eye = workloads.analytic_camera(cam, w, h)
+        r = refrun.run({}, w, h, rays, eye, spp=spp, shader=kernel, tables=tables, **uni)
+        meta = dict(kernel=kernel, camera=cam, width=w, height=h, spp=spp, time0=1.25, dtime=0.0625, uniforms=uni)
+        path = os.path.join(OUT, analytic_name(kernel, cam, w, h, spp, uni))
+        np.savez_compressed(path, color=r["color"], normal=r["normal"], pos=r["pos"].view(np.uint16),
+                            tridx=r["tridx"].astype(np.int16), rays=rays, eye=eye, meta=json.dumps(meta))
+        print("wrote", path, os.path.getsize(path), "ids", np.unique(r["tridx"]).tolist())
 
 
 def gen_filter():
@@ -220,7 +254,7 @@ def main():
     if not refrun.available():
         sys.exit("reference oracle unavailable: run `make ref` in the container that holds /root/reference")
     steps = dict(camera=gen_camera, semantics=gen_semantics, kat=gen_kat, trace=gen_trace, filter=gen_filter,
-                 ids=gen_ids)
+                 ids=gen_ids, analytic=gen_analytic)
     for k, fn in steps.items():
         if a.only in (None, k):
             fn()
