@@ -160,6 +160,10 @@ int rt_set_stream(rt_ctx *ctx, void *hip_stream);
  * (links and ranges in bounds) and re-packed privately into aligned device records. */
 int rt_upload(rt_ctx *ctx, int slot, const void *bytes, size_t nbytes);
 int rt_set_table(rt_ctx *ctx, int table, const void *bytes, size_t nbytes);
+/* Blocking copy of a Q-table slot (7..10) back to the host, e.g. the table RT_KERNEL_TRACE3_RL has learned.
+ * The reference never reads its Q-table back (reference src/QTable.cpp:138-146 only uploads); the GL
+ * counterpart would be glGetBufferSubData on QTable::QTableSsbo / QVisitsSsbo. */
+int rt_download(rt_ctx *ctx, int slot, void *dst, size_t nbytes);
 
 /* (Re)allocate and clear the images for a width x height frame. */
 int rt_resize(rt_ctx *ctx, int width, int height);

@@ -39,6 +39,12 @@ class OrcAnalyticParams(ctypes.Structure):
                 ("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32), ("y1", ctypes.c_int32)]
 
 
+class OrcQTable(ctypes.Structure):
+    _fields_ = [("normals", ctypes.c_void_p), ("centres", ctypes.c_void_p), ("qt", ctypes.c_void_p),
+                ("visits", ctypes.c_void_p), ("num_cells", ctypes.c_int32), ("num_q", ctypes.c_int32),
+                ("num_points", ctypes.c_int32), ("max_theta", ctypes.c_int32), ("max_phi", ctypes.c_int32)]
+
+
 ANALYTIC_KERNELS = {"trace": 0, "trace1": 1, "trace2": 2}
 TABLE_BYTES = {"sobol": 65536, "scramble": 131072, "ranking": 131072, "ltc1": 65536, "ltc2": 65536}
 
@@ -56,6 +62,9 @@ def lib():
         L.orc_trace.restype = None
         L.orc_trace_analytic.argtypes = [ctypes.c_int32, ctypes.POINTER(OrcAnalyticParams), vp, vp, vp, vp]
         L.orc_trace_analytic.restype = None
+        L.orc_trace_rl.argtypes = [ctypes.POINTER(OrcScene), ctypes.POINTER(OrcQTable), ctypes.POINTER(OrcTraceParams),
+                                   vp, vp, vp, vp]
+        L.orc_trace_rl.restype = None
         L.orc_filter_pass.argtypes = [ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int32, vp, vp, vp,
                                       ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_int32]
         L.orc_filter_pass.restype = None
@@ -127,6 +136,42 @@ def trace(scene, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.
                     tridx.ctypes.data, visits.ctypes.data, stats.ctypes.data)
         stats_sum += stats
     return dict(stats_sum=stats_sum, color=color, normal=normal, pos=pos.view(np.float16), tridx=tridx, visits=visits, stats=stats)
+
+
+class QTable:
+    """Mutable Q-table state (slots 7..10 of the scene byte streams); updated in place by trace_rl."""
+
+    def __init__(self, buffers, num_points=100, max_theta=10, max_phi=10):
+        self.normals = np.frombuffer(buffers[7], np.float32).copy()
+        self.centres = np.frombuffer(buffers[8], np.float32).copy()
+        self.qt = np.frombuffer(buffers[9], np.float32).copy()
+        self.visits = np.frombuffer(buffers[10], np.int32).copy()
+        self.c = OrcQTable(self.normals.ctypes.data, self.centres.ctypes.data, self.qt.ctypes.data,
+                           self.visits.ctypes.data, self.visits.size, self.qt.size, num_points, max_theta, max_phi)
+
+
+def trace_rl(scene, qtable, width, height, rays, eye, time, blend_factor, max_bounces=5, color=None, oob="llvmpipe",
+             num_emitters=None):
+    """One dispatch of trace3.cs with main() calling traceRL; paths run sequentially in raster order."""
+    L = lib()
+    color = np.zeros((height, width, 4), np.float32) if color is None else np.ascontiguousarray(color, np.float32).copy()
+    normal = np.zeros((height, width, 4), np.int8)
+    pos = np.zeros((height, width, 4), np.uint16)
+    tridx = np.full((height, width), -2, np.int32)
+    rays = np.asarray(rays, np.float32).reshape(4, 3)
+    p = OrcTraceParams()
+    p.width, p.height = width, height
+    p.eye[:] = [float(np.float32(v)) for v in eye]
+    p.ray00[:], p.ray01[:], p.ray10[:], p.ray11[:] = rays[0].tolist(), rays[1].tolist(), rays[2].tolist(), rays[3].tolist()
+    p.max_bounces = max_bounces
+    p.num_emitters = scene.c.num_emitters if num_emitters is None else num_emitters
+    p.max_follows = 1000
+    p.time, p.blend_factor = float(np.float32(time)), float(np.float32(blend_factor))
+    if oob == "llvmpipe":
+        p.oob_seeds[:] = [float(np.array([max_bounces], np.int32).view(np.float32)[0]), p.blend_factor, p.time]
+    L.orc_trace_rl(ctypes.byref(scene.c), ctypes.byref(qtable.c), ctypes.byref(p), color.ctypes.data, normal.ctypes.data,
+                   pos.ctypes.data, tridx.ctypes.data)
+    return dict(color=color, normal=normal, pos=pos.view(np.float16), tridx=tridx)
 
 
 def trace_analytic(kernel, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.0625, importance=1, mis=1,

@@ -27,11 +27,13 @@ def run(scene_buffers, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dt
         num_emitters=0, importance=1, instrument=True, filter_iters=0, c_phi0=3.3, n_phi0=1e-2, p_phi0=5.5,
         repeat=1, init_color=None, init_normal=None, init_pos=None, stats_per_sample=False, timeout=3600,
         shader="trace3", phong_exponent=128.0, specular_factor=0.2, roughness=0.5, mis=1, use_blue_noise=1,
-        tables=None):
+        tables=None, seq=None):
     """scene_buffers: {slot: bytes} for slots 3..10 (missing → zeros). Returns dict of numpy arrays
     (row 0 = bottom image row, as GL) plus 'trace_ms' / 'filter_ms' lists and 'log'.
     shader: "trace3" (live kernel) | "trace" | "trace1" | "trace2"; tables: {"sobol"|"scramble"|"ranking"|"ltc1"|
-    "ltc2": bytes} for trace1 / trace2 (the reference's res/*.data contents)."""
+    "ltc2": bytes} for trace1 / trace2 (the reference's res/*.data contents).
+    shader "trace3rl" = trace3.cs with main() calling traceRL; seq = float32 [n,8] {eye, dir, time, blendFactor}:
+    one dispatch per record with all corner rays = dir (use width = height = 1 for one path per dispatch)."""
     if not available():
         raise RuntimeError("reference oracle unavailable (no oracle/_ref/run_ref_shader or no reference dir)")
     names = {3: "nodes", 4: "tris", 5: "mtls", 6: "emitters", 7: "vnormals", 8: "vcentres", 9: "qtable",
@@ -67,6 +69,10 @@ def run(scene_buffers, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dt
                 p = os.path.join(tmp, key + ".bin")
                 np.ascontiguousarray(arr, dtype=dt).tofile(p)
                 lines.append(f"{key}={p}")
+        if seq is not None:
+            sp = os.path.join(tmp, "seq.f32")
+            np.ascontiguousarray(seq, np.float32).reshape(-1, 8).tofile(sp)
+            lines.append(f"seq={sp}")
         job = os.path.join(tmp, "job.txt")
         with open(job, "w") as f:
             f.write("\n".join(lines) + "\n")
@@ -92,6 +98,10 @@ def run(scene_buffers, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dt
         res["tridx"] = load(".tridx.i32", np.int32, 1)
         res["visits"] = load(".visits.i32", np.int32, 1)
         res["stats"] = load(".stats.i32", np.int32, 4)
+        for suffix, key, dt in ((".qtable.f32", "qtable", np.float32), (".qvisits.i32", "qvisits", np.int32),
+                                (".seqcolor.f32", "seqcolor", np.float32)):
+            fp = f"{tmp}/o{suffix}"
+            res[key] = np.fromfile(fp, dtype=dt) if os.path.exists(fp) else None
         res["filter"] = []
         for i in range(filter_iters):
             res["filter"].append(load(f".filter{i}.f16", np.float16, 4))

@@ -589,6 +589,255 @@ void orc_trace(const orc_scene *scene, const orc_trace_params *p, float *color, 
     }
 }
 
+/* ------------------------------------------------------------------ Q-table guided tracing
+ * traceRL (trace3.cs:695-791) with qtablehelper.glsl.  The reference updates the shared Q-table and visit
+ * counts without atomics from every invocation at once, so a frame's result depends on the execution order;
+ * this restatement runs the paths one after the other in raster order (y outer, x inner), which is one of the
+ * orders the reference's program admits, and is pinned against the reference executed one path per dispatch
+ * (tests/golden/rl_sequence_*.npz).  Out-of-range buffer reads give 0 and out-of-range writes are dropped. */
+typedef struct {
+    const ctx_t *c;
+    const orc_qtable *q;
+} qctx_t;
+
+static inline int f2i(float x) { /* float -> int as the oracle platform converts (cvttps2dq): INT_MIN when out of range */
+    return (x >= -2147483648.0f && x < 2147483648.0f) ? (int)x : (int)0x80000000u;
+}
+/* Buffer addressing of the oracle platform: the byte offset index * stride is formed in 32 bits (it wraps), and
+ * an access is in range when that offset lies inside the buffer.  An index of INT_MIN + k (what int(NaN) + k
+ * gives, e.g. findIndex with |ctheta| > 1) therefore addresses element k of a 4-byte array. */
+static inline int wrapIndex(int i, unsigned stride, int count) {
+    unsigned off = (unsigned)i * stride;
+    return (off / stride < (unsigned)count && off % stride == 0) ? (int)(off / stride) : -1;
+}
+static inline v3 qNormal(const orc_qtable *q, int i) {
+    i = wrapIndex(i, 16u, q->num_cells);
+    return i >= 0 ? ld3(q->normals + 4 * (size_t)i) : V3(0, 0, 0);
+}
+static inline v3 qCentre(const orc_qtable *q, int i) {
+    i = wrapIndex(i, 16u, q->num_cells);
+    return i >= 0 ? ld3(q->centres + 4 * (size_t)i) : V3(0, 0, 0);
+}
+static inline float qRead(const orc_qtable *q, int i) {
+    i = wrapIndex(i, 4u, q->num_q);
+    return i >= 0 ? q->qt[i] : 0.0f;
+}
+static inline int qVisits(const orc_qtable *q, int i) {
+    i = wrapIndex(i, 4u, q->num_cells);
+    return i >= 0 ? q->visits[i] : 0;
+}
+
+/* qtablehelper.glsl:81-94 */
+static inline float fastacos(float x) {
+    float negate = (x < 0) ? 1.0f : 0.0f;
+    x = fabsf(x);
+    float ret = -0.0187293f;
+    ret = ret * x;
+    ret = ret + 0.0742610f;
+    ret = ret * x;
+    ret = ret - 0.2121144f;
+    ret = ret * x;
+    ret = ret + 1.5707288f;
+    ret = ret * sqrtf(1.0f - x);
+    ret = ret - (2 * negate) * ret;
+    return negate * PI_F + ret;
+}
+/* qtablehelper.glsl:176-196 */
+static unsigned findCell(const orc_qtable *q, v3 pos, int objId, v3 normal) {
+    float nearest = 10000.0f;
+    unsigned nearestIdx = 0;
+    for (int i = 0; i < q->num_points; i++) {
+        v3 nv = qNormal(q, objId * q->num_points + i);
+        if (nv.x != 0.0f || nv.y != 0.0f || nv.z != 0.0f) {
+            if (dot3(normalize3(nv), normalize3(normal)) > 0.866f) {
+                v3 d = vsub(qCentre(q, objId * q->num_points + i), pos);
+                float len = sqrtf(dot3(d, d));
+                if (len < nearest) { nearestIdx = (unsigned)i; nearest = len; }
+            }
+        }
+    }
+    return nearestIdx;
+}
+/* qtablehelper.glsl:212-224 */
+static float maxQ(const orc_qtable *q, unsigned idx, int objId) {
+    float mq = 0;
+    int base = q->num_points * q->max_theta * q->max_phi * objId + q->max_theta * q->max_phi * (int)idx;
+    for (int i = 0; i < q->max_theta; i++)
+        for (int j = 0; j < q->max_phi; j++) mq = fmaxf(mq, qRead(q, base + i * q->max_phi + j));
+    return mq;
+}
+static inline v3 orthogonal(v3 v) { /* qtablehelper.glsl:231-235 */
+    return fabsf(v.x) > fabsf(v.z) ? V3(-v.y, v.x, 0.0f) : V3(0.0f, -v.z, v.y);
+}
+/* qtablehelper.glsl:245-274 */
+static int findIndex(const orc_qtable *q, unsigned idx, int objId, v3 dir, v3 n) {
+    v3 normdir = normalize3(dir), nvec = normalize3(n);
+    v3 uvec = normalize3(orthogonal(nvec)), vvec = normalize3(cross3(nvec, uvec));
+    float np = dot3(nvec, normdir);
+    int u = f2i(np * (float)q->max_theta);
+    float up = dot3(uvec, normdir), vp = dot3(vvec, normdir);
+    float ctheta = up / sqrtf(1 - np * np);
+    float theta = (vp > 0) ? fastacos(ctheta) : TWO_PI_F - fastacos(ctheta);
+    int v = f2i((theta / TWO_PI_F) * (float)q->max_phi);
+    int base = q->num_points * q->max_theta * q->max_phi * objId + q->max_theta * q->max_phi * (int)idx;
+    return (int)((unsigned)base + (unsigned)u * (unsigned)q->max_phi + (unsigned)v);
+}
+/* qtablehelper.glsl:286-318 */
+static void updateQtable(ctx_t *c, orc_qtable *q, const SI_t *oSI, const SI_t *hSI, v3 dir, float lastAttenuation,
+                         int prevIdx, int *nextIdx) {
+    const int oObj = fetchTri(c, oSI->tridx)->objId, hObj = fetchTri(c, hSI->tridx)->objId;
+    unsigned idxPrev = prevIdx >= 0 ? (unsigned)prevIdx : findCell(q, oSI->point, oObj, oSI->normal);
+    unsigned idxCurr = findCell(q, hSI->point, hObj, hSI->normal);
+    *nextIdx = (int)idxCurr;
+    float update;
+    const mtl_t *hm = fetchMtl(c, hSI->matidx);
+    if (hm->emitter) {
+        v3 ke = ld3(hm->Ke);
+        update = fminf(fmaxf(sqrtf(dot3(ke, ke)), 0.0f), 1.0f);
+    } else {
+        update = lastAttenuation * maxQ(q, idxCurr, hObj);
+    }
+    int idxQ = findIndex(q, idxPrev, oObj, vneg(dir), oSI->normal);
+    int vi = q->num_points * oObj + (int)idxPrev;
+    float alpha = 1.0f / (1.0f + (float)qVisits(q, vi));
+    vi = wrapIndex(vi, 4u, q->num_cells);
+    if (vi >= 0) q->visits[vi]++;
+    idxQ = wrapIndex(idxQ, 4u, q->num_q);
+    if (idxQ >= 0) q->qt[idxQ] = (1 - alpha) * q->qt[idxQ] + alpha * update;
+}
+/* qtablehelper.glsl:328-354; falling off the end (a table row without a positive finite sum) is undefined in
+ * the reference and returns patch (0,0) with pdf 0 here */
+static void sampleCdf(const orc_qtable *q, int idx, int objId, float rnd_, float *pdf, int *j_out, int *k_out) {
+    float cdf = 0, den = 0;
+    int base = q->num_points * q->max_phi * q->max_theta * objId + q->max_phi * q->max_theta * idx;
+    for (int j = 0; j < q->max_theta; j++)
+        for (int k = 0; k < q->max_phi; k++) den += qRead(q, base + j * q->max_phi + k);
+    for (int j = 0; j < q->max_theta; j++)
+        for (int k = 0; k < q->max_phi; k++) {
+            cdf += qRead(q, base + j * q->max_phi + k);
+            if (cdf / den >= rnd_) {
+                *pdf = qRead(q, base + j * q->max_phi + k) / den;
+                *j_out = j; *k_out = k;
+                return;
+            }
+        }
+    *pdf = 0; *j_out = 0; *k_out = 0;
+}
+/* sampleScatteringDir, qtablehelper.glsl:399-419, with uniformSamplePatch (:378-389) and aroundv (:362-369) */
+static v3 sampleScatteringDir(ctx_t *c, const orc_qtable *q, const SI_t *SI, int QIdx, float r0, float r1, float r2,
+                              float *outpdf) {
+    const int obj = fetchTri(c, SI->tridx)->objId;
+    unsigned idx = QIdx >= 0 ? (unsigned)QIdx : findCell(q, SI->point, obj, SI->normal);
+    float pdf;
+    int pj, pk;
+    sampleCdf(q, (int)idx, obj, r0, &pdf, &pj, &pk);
+    int nu = pk, nv = pj;
+    float u = ((float)nu + r1) / (float)q->max_phi, v = ((float)nv + r2) / (float)q->max_theta;
+    v3 d = V3(cosf(TWO_PI_F * v) * sqrtf(1 - u * u), sinf(TWO_PI_F * v) * sqrtf(1 - u * u), u);
+    v3 nvec = normalize3(SI->normal), uvec = normalize3(orthogonal(nvec)), vvec = normalize3(cross3(nvec, uvec));
+    v3 w = normalize3(vadd(vadd(vscale(uvec, d.x), vscale(vvec, d.y)), vscale(nvec, d.z)));
+    *outpdf = ((pdf * (float)q->max_phi) * (float)q->max_theta) / TWO_PI_F;
+    return w;
+}
+
+/* trace3.cs:695-791 */
+static void tracePathRL(ctx_t *c, orc_qtable *q, v3 origin, v3 dir, v3 invdir, int maxBounces, path_t *out) {
+    v3 L = V3(0, 0, 0), beta = V3(1, 1, 1);
+    const v3 SKY = V3(0.89f, 0.96f, 1.00f);
+    int prevQIdx = -1;
+    SI_t prevSI;
+    memset(&prevSI, 0, sizeof prevSI);
+    for (int bounces = 0;; ++bounces) {
+        SI_t SI;
+        intersectGeometry(c, origin, dir, invdir, &SI);
+        int found = (SI.tridx != -1), isAreaLight = 0;
+        if (bounces == 0) {
+            out->hit0 = found;
+            out->tridx0 = SI.tridx;
+            out->visits0 = c->last_iterations;
+            out->point0 = found ? SI.point : V3(0, 0, 0);
+            out->normal0 = found ? SI.normal : V3(0, 0, 0);
+        }
+        if (found) {
+            const mtl_t *m = fetchMtl(c, SI.matidx);
+            if (m->emitter) {
+                if (L.x != L.x || L.y != L.y || L.z != L.z) { out->L = V3(1.0f, 0.0f, 1.0f); return; }
+                L = vadd(L, vscale(vmul(beta, ld3(m->Ke)), 30.0f));
+                isAreaLight = 1;
+            }
+        } else {
+            L = vadd(L, vmul(beta, SKY));
+        }
+        if (bounces > 0) {
+            int temp;
+            updateQtable(c, q, &prevSI, &SI, dir, fmaxf(beta.x, fmaxf(beta.y, beta.z)), prevQIdx, &temp);
+            prevQIdx = temp;
+        }
+        if (!found || bounces >= maxBounces || isAreaLight) break;
+        origin = vadd(SI.point, vscale(SI.normal, EPSILON_F));
+        float r0, r1, r2, pdf;
+        randvec3(c, bounces, &r0, &r1, &r2);
+        v3 wi = sampleScatteringDir(c, q, &SI, prevQIdx, r0, r1, r2, &pdf); /* sampleOutDirRL, trace3.cs:609-616 */
+        v3 f = brdf(c, &SI, wi, vneg(dir), SI.normal);
+        beta = vmul(beta, vdivs(vscale(f, dot3(normalize3(SI.normal), normalize3(wi))), pdf));
+        dir = wi;
+        invdir = V3(1.0f / wi.x, 1.0f / wi.y, 1.0f / wi.z);
+        float rr_rand = randfloat(c, bounces);
+        float rrbetamax = fmaxf(beta.x, fmaxf(beta.y, beta.z));
+        if (bounces > 3) {
+            float qq = fmaxf(0.05f, 1 - rrbetamax);
+            if (rr_rand < qq) break;
+            beta = vdivs(beta, (1.0f - qq));
+        }
+        prevSI = SI;
+    }
+    out->L = L;
+}
+
+void orc_trace_rl(const orc_scene *scene, orc_qtable *q, const orc_trace_params *p, float *color, int8_t *normal,
+                  uint16_t *pos, int32_t *tridx) {
+    const int W = p->width, H = p->height;
+    int x0 = p->x0, y0 = p->y0, x1 = p->x1, y1 = p->y1;
+    if (x0 == 0 && y0 == 0 && x1 == 0 && y1 == 0) { x1 = W; y1 = H; }
+    const v3 eye = ld3(p->eye), r00 = ld3(p->ray00), r01 = ld3(p->ray01), r10 = ld3(p->ray10), r11 = ld3(p->ray11);
+    for (int y = y0; y < y1; y++) { /* sequential on purpose: the Q-table is shared mutable state */
+        for (int x = x0; x < x1; x++) {
+            ctx_t c;
+            memset(&c, 0, sizeof c);
+            c.sc = scene;
+            c.px = x;
+            c.py = y;
+            c.time = p->time;
+            c.max_follows = p->max_follows > 0 ? p->max_follows : 1000;
+            c.num_emitters_uniform = p->num_emitters;
+            memcpy(c.oob_seeds, p->oob_seeds, sizeof c.oob_seeds);
+            float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
+            v3 dir = normalize3(mix3(mix3(r00, r01, pyf), mix3(r10, r11, pyf), pxf));
+            v3 inv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+            path_t path;
+            tracePathRL(&c, q, eye, dir, inv, p->max_bounces, &path);
+            const size_t i = (size_t)y * W + x;
+            v3 old = V3(0, 0, 0);
+            if (p->blend_factor > 0.0f) old = V3(color[4 * i], color[4 * i + 1], color[4 * i + 2]);
+            v3 fin = mix3(path.L, old, p->blend_factor);
+            color[4 * i] = fin.x; color[4 * i + 1] = fin.y; color[4 * i + 2] = fin.z; color[4 * i + 3] = 1.0f;
+            if (normal) {
+                normal[4 * i] = orc_f32_to_snorm8(path.normal0.x);
+                normal[4 * i + 1] = orc_f32_to_snorm8(path.normal0.y);
+                normal[4 * i + 2] = orc_f32_to_snorm8(path.normal0.z);
+                normal[4 * i + 3] = 0;
+            }
+            if (pos) {
+                pos[4 * i] = orc_f32_to_f16_rtz(path.point0.x);
+                pos[4 * i + 1] = orc_f32_to_f16_rtz(path.point0.y);
+                pos[4 * i + 2] = orc_f32_to_f16_rtz(path.point0.z);
+                pos[4 * i + 3] = orc_f32_to_f16_rtz(1.0f);
+            }
+            if (tridx) tridx[i] = path.tridx0;
+        }
+    }
+}
+
 /* ------------------------------------------------------------------ analytic kernels
  * trace.cs (box room), trace1.cs (box room + rectangle light, MIS, blue-noise sampler), trace2.cs (LTC area
  * lights).  They share random.glsl with trace3; their own PI macros are unparenthesised (trace.cs:33-35,

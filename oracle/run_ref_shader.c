@@ -55,6 +55,7 @@ GLFN(PFNGLGENBUFFERSPROC, glGenBuffers);
 GLFN(PFNGLBINDBUFFERPROC, glBindBuffer);
 GLFN(PFNGLBUFFERDATAPROC, glBufferData);
 GLFN(PFNGLBINDBUFFERBASEPROC, glBindBufferBase);
+GLFN(PFNGLGETBUFFERSUBDATAPROC, glGetBufferSubData);
 GLFN(PFNGLTEXSTORAGE2DPROC, glTexStorage2D);
 GLFN(PFNGLBINDIMAGETEXTUREPROC, glBindImageTexture);
 GLFN(PFNGLDISPATCHCOMPUTEPROC, glDispatchCompute);
@@ -90,7 +91,7 @@ static void loadGL(void) {
     LOAD(glGetShaderInfoLog); LOAD(glCreateProgram); LOAD(glAttachShader); LOAD(glLinkProgram);
     LOAD(glGetProgramiv); LOAD(glGetProgramInfoLog); LOAD(glUseProgram); LOAD(glGetUniformLocation);
     LOAD(glUniform1i); LOAD(glUniform2i); LOAD(glUniform1f); LOAD(glUniform1fv); LOAD(glUniform3fv);
-    LOAD(glGenBuffers); LOAD(glBindBuffer); LOAD(glBufferData); LOAD(glBindBufferBase); LOAD(glTexStorage2D);
+    LOAD(glGenBuffers); LOAD(glBindBuffer); LOAD(glBufferData); LOAD(glBindBufferBase); LOAD(glGetBufferSubData); LOAD(glTexStorage2D);
     LOAD(glBindImageTexture); LOAD(glDispatchCompute); LOAD(glMemoryBarrier); LOAD(glGenFramebuffers);
     LOAD(glBindFramebuffer); LOAD(glFramebufferTexture2D); LOAD(glCheckFramebufferStatus); LOAD(glDrawBuffers);
     LOAD(glGenVertexArrays); LOAD(glBindVertexArray); LOAD(glVertexAttribPointer);
@@ -220,6 +221,8 @@ static GLuint makeTex(GLenum fmt, int w, int h) {
     p_glTexParameteri(GL_TEXTURE_2D, GL_TEXTURE_WRAP_T, GL_REPEAT);
     return t;
 }
+static GLuint ssboId[16];
+static size_t ssboSize[16];
 static void ssbo(int binding, const char *key) {
     const char *path = jobStr(key, NULL);
     size_t n = 0;
@@ -235,6 +238,8 @@ static void ssbo(int binding, const char *key) {
     if (n) p_glBufferData(GL_SHADER_STORAGE_BUFFER, (GLsizeiptr)n, bytes, GL_STATIC_DRAW);
     else p_glBufferData(GL_SHADER_STORAGE_BUFFER, sizeof zeros, zeros, GL_STATIC_DRAW);
     p_glBindBufferBase(GL_SHADER_STORAGE_BUFFER, (GLuint)binding, b);
+    ssboId[binding] = b;
+    ssboSize[binding] = n;
     free(bytes);
 }
 static int nextPowerOfTwo(int x) { /* reference src/Tracer.cpp:3-12 */
@@ -313,6 +318,7 @@ int main(int argc, char **argv) {
         if (!strcmp(shader, "trace")) { files = filesBox; nfiles = 2; variant = 0; }
         else if (!strcmp(shader, "trace1")) { files = filesBn; nfiles = 2; variant = 1; }
         else if (!strcmp(shader, "trace2")) { files = filesLtc; nfiles = 2; variant = 2; }
+        else if (!strcmp(shader, "trace3rl")) variant = 4; /* trace3.cs with main() calling traceRL (:695-791) */
         else if (strcmp(shader, "trace3")) { fprintf(stderr, "unknown shader=%s\n", shader); return 2; }
         const char *extraImages = "uniform image2D posbuffer;\n"
                                   "layout(binding = 3, r32i) uniform iimage2D o_tridx;\n"
@@ -349,7 +355,12 @@ int main(int argc, char **argv) {
                 src = replaceOnce(src, NULL, "texture2D(ltc_mat, uv)", "texture(ltc_mat, uv)");
                 src = replaceOnce(src, NULL, "texture2D(ltc_mag, uv)", "texture(ltc_mag, uv)");
             }
-            if (i == 0 && instrument && variant == 3) {
+            if (i == 0 && variant == 4) {
+                /* the reference's main() calls trace(); its Q-table guided entry point is selected instead */
+                src = replaceOnce(src, "void main(void)", "vec3 color = trace(eye, dir, 1.0 / dir);",
+                                  "vec3 color = traceRL(eye, dir, 1.0 / dir);");
+            }
+            if (i == 0 && instrument && variant >= 3) {
                 src = replaceOnce(src, NULL, "uniform image2D posbuffer;", extraImages);
                 src = replaceOnce(src, "int intersectTriangles(", "const triangle tri = triangles[i];",
                                   "const triangle tri = triangles[i]; g_tests++;");
@@ -357,7 +368,8 @@ int main(int argc, char **argv) {
                                   "      g_iter = iterations; g_rays++; g_visits += iterations; SI.tridx = -1;");
                 src = replaceOnce(src, "void intersectGeometry(", "  SI.tridx = rettridx;",
                                   "  g_iter = iterations; g_rays++; g_visits += iterations; SI.tridx = rettridx;");
-                src = replaceOnce(src, "vec3 trace(vec3 origin, vec3 dir, vec3 invdir)",
+                src = replaceOnce(src, variant == 4 ? "vec3 traceRL(vec3 origin, vec3 dir, vec3 invdir)"
+                                                    : "vec3 trace(vec3 origin, vec3 dir, vec3 invdir)",
                                   "bool foundIntersection = (SI.tridx != -1);",
                                   "bool foundIntersection = (SI.tridx != -1);\n"
                                   "    if(bounces == 0) { imageStore(o_tridx, px, ivec4(SI.tridx));"
@@ -366,7 +378,7 @@ int main(int argc, char **argv) {
                                   "imageStore(framebuffer, pix, vec4(finalColor, 1.0));\n"
                                   "  imageStore(o_stats, pix, ivec4(g_rays, g_visits, g_tests, floatBitsToInt(rand_seeds[-1 - (pix.x % 3)])));");
             }
-            if (i == 0 && instrument && variant != 3) {
+            if (i == 0 && instrument && variant < 3) {
                 /* primary-hit object id: box index, 100 + rectangle index, -1 for a miss; o_visits = number of
                  * bounces that found a hit is not recorded (the analytic kernels have no traversal). */
                 const char *anchor = "vec3 trace(vec3 origin, vec3 dir) {";
@@ -432,8 +444,20 @@ int main(int argc, char **argv) {
         float eye[3], r00[3], r01[3], r10[3], r11[3];
         jobVec3("eye", eye); jobVec3("ray00", r00); jobVec3("ray01", r01); jobVec3("ray10", r10); jobVec3("ray11", r11);
 
+        /* seq=file: one dispatch per 8-float record {eye.xyz, dir.xyz, time, blendFactor}; all four corner rays are
+         * set to dir, so that on a 1x1 image exactly one path runs per dispatch (a deterministic order for the
+         * Q-table updates of traceRL).  The colour image after every dispatch is appended to <out>.seqcolor.f32. */
+        size_t seqBytes = 0;
+        float *seq = NULL;
+        if (jobStr("seq", NULL)) {
+            seq = (float *)readFile(jobStr("seq", NULL), &seqBytes);
+            if (!seq || seqBytes % 32) { fprintf(stderr, "bad seq file\n"); return 2; }
+        }
+        const int nseq = (int)(seqBytes / 32);
+        float *seqColor = nseq ? malloc((size_t)nseq * npx * 16) : NULL;
+        const int ndispatch = nseq ? nseq : spp;
         for (int rep = 0; rep < repeat; rep++) {
-            for (int k = 0; k < spp; k++) {
+            for (int k = 0; k < ndispatch; k++) {
                 const int frame = frame0 + k;
                 const double t0 = now();
                 p_glUseProgram(prog);
@@ -458,6 +482,16 @@ int main(int argc, char **argv) {
                 p_glUniform1i(p_glGetUniformLocation(prog, "multipleImportanceSampled"), jobInt("mis", 1));
                 p_glUniform1i(p_glGetUniformLocation(prog, "useBlueNoise"), jobInt("use_blue_noise", 1));
                 p_glUniform1i(p_glGetUniformLocation(prog, "frameIndex"), frame);
+                if (nseq) {
+                    const float *r = seq + 8 * k;
+                    p_glUniform3fv(p_glGetUniformLocation(prog, "eye"), 1, r);
+                    p_glUniform3fv(p_glGetUniformLocation(prog, "ray00"), 1, r + 3);
+                    p_glUniform3fv(p_glGetUniformLocation(prog, "ray01"), 1, r + 3);
+                    p_glUniform3fv(p_glGetUniformLocation(prog, "ray10"), 1, r + 3);
+                    p_glUniform3fv(p_glGetUniformLocation(prog, "ray11"), 1, r + 3);
+                    p_glUniform1f(p_glGetUniformLocation(prog, "time"), r[6]);
+                    p_glUniform1f(p_glGetUniformLocation(prog, "blendFactor"), r[7]);
+                }
                 p_glBindImageTexture(0, colorTex, 0, GL_FALSE, 0, GL_READ_WRITE, GL_RGBA32F);
                 p_glBindImageTexture(1, normTex, 0, GL_FALSE, 0, GL_WRITE_ONLY, GL_RGBA8_SNORM);
                 p_glBindImageTexture(2, posTex, 0, GL_FALSE, 0, GL_WRITE_ONLY, GL_RGBA16F);
@@ -466,12 +500,18 @@ int main(int argc, char **argv) {
                     p_glBindImageTexture(4, visitsTex, 0, GL_FALSE, 0, GL_WRITE_ONLY, GL_R32I);
                     p_glBindImageTexture(5, statsTex, 0, GL_FALSE, 0, GL_WRITE_ONLY, GL_RGBA32I);
                 }
-                p_glDispatchCompute((GLuint)(nextPowerOfTwo(W) / wg[0]), (GLuint)(nextPowerOfTwo(H) / wg[1]), 1);
+                GLuint gx = (GLuint)(nextPowerOfTwo(W) / wg[0]), gy = (GLuint)(nextPowerOfTwo(H) / wg[1]);
+                if (nseq) { gx = gx ? gx : 1; gy = gy ? gy : 1; } /* a 1x1 image still needs one work group */
+                p_glDispatchCompute(gx, gy, 1);
                 p_glMemoryBarrier(GL_SHADER_IMAGE_ACCESS_BARRIER_BIT);
                 p_glMemoryBarrier(GL_SHADER_STORAGE_BARRIER_BIT);
                 p_glFinish();
-                printf("trace rep %d sample %d ms %.3f\n", rep, k, 1e3 * (now() - t0));
+                if (!nseq || k < 4) printf("trace rep %d sample %d ms %.3f\n", rep, k, 1e3 * (now() - t0));
                 fflush(stdout);
+                if (nseq) {
+                    p_glBindTexture(GL_TEXTURE_2D, colorTex);
+                    p_glGetTexImage(GL_TEXTURE_2D, 0, GL_RGBA, GL_FLOAT, seqColor + (size_t)k * npx * 4);
+                }
                 if (instrument && rep == 0 && jobInt("dump_stats_per_sample", 0)) {
                     int *st = malloc(npx * 16);
                     p_glBindTexture(GL_TEXTURE_2D, statsTex);
@@ -484,6 +524,15 @@ int main(int argc, char **argv) {
             }
         }
         checkGL("trace");
+        if (nseq) writeFile(out, ".seqcolor.f32", seqColor, (size_t)nseq * npx * 16);
+        for (int b = 9; b <= 10; b++) /* Q-table and visit counts after the run (qtablehelper.glsl:26-32) */
+            if (ssboSize[b]) {
+                void *buf = malloc(ssboSize[b]);
+                p_glBindBuffer(GL_SHADER_STORAGE_BUFFER, ssboId[b]);
+                p_glGetBufferSubData(GL_SHADER_STORAGE_BUFFER, 0, (GLsizeiptr)ssboSize[b], buf);
+                writeFile(out, b == 9 ? ".qtable.f32" : ".qvisits.i32", buf, ssboSize[b]);
+                free(buf);
+            }
     }
 
     /* ---------------- readback of the tracer outputs */

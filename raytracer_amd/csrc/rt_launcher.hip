@@ -15,6 +15,7 @@
 
 #include "rt_device.h"
 #include "analytic.h"
+#include "trace3_rl.h"
 #include "wavefront.h"
 
 hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace_params &p, const rt_rect &tile,
@@ -367,6 +368,20 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
     }
 }
 
+int rt_download(rt_ctx *c, int slot, void *dst, size_t nbytes) {
+    if (!c || !dst) return RT_EINVAL;
+    if (slot < RT_SLOT_VORONOI_NORMALS || slot > RT_SLOT_QVISITS)
+        return fail(c, RT_EINVAL, "rt_download: only slots 7..10 (the Q-table state) are kept as uploaded");
+    if (!c->raw[slot].p) return fail(c, RT_ESTATE, "rt_download: slot " + std::to_string(slot) + " was never uploaded");
+    if (nbytes != c->raw[slot].bytes)
+        return fail(c, RT_EINVAL, "rt_download: size mismatch, need " + std::to_string(c->raw[slot].bytes));
+    int r = bind(c);
+    if (r) return r;
+    HIP_TRY(c, hipMemcpyAsync(dst, c->raw[slot].p, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
 int rt_set_table(rt_ctx *c, int table, const void *bytes, size_t nbytes) {
     if (!c) return RT_EINVAL;
     if (table < 0 || table > RT_TABLE_LTC2 || !bytes) return fail(c, RT_EINVAL, "rt_set_table: bad argument");
@@ -560,6 +575,41 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
                                          c->profile ? c : nullptr);
         span.end();
         if (e != hipSuccess) return hipFail(c, e, "wavefront launch");
+        return RT_OK;
+    }
+    case RT_KERNEL_TRACE3_RL: {
+        // traceRL (reference trace3.cs:695-791): the scene of trace3 plus the Q-table state of slots 7..10.
+        if (!c->boxes.p || !c->tris48.p || !c->mtls.p)
+            return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
+        if (c->maxTriEnd > c->numTris)
+            return fail(c, RT_ECORRUPT, "rt_trace: a leaf references triangles beyond the uploaded triangle stream");
+        for (int slot = RT_SLOT_VORONOI_NORMALS; slot <= RT_SLOT_QVISITS; ++slot)
+            if (!c->raw[slot].p) return fail(c, RT_ESTATE, "rt_trace: the Q-table kernel needs slots 7..10 uploaded");
+        if (p->numPoints <= 0 || p->maxTheta <= 0 || p->maxPhi <= 0 ||
+            (long long)p->numPoints * p->maxTheta * p->maxPhi > (1ll << 24))
+            return fail(c, RT_EINVAL, "rt_trace: numPoints / maxTheta / maxPhi out of range");
+        RtScene sc;
+        RtImages img;
+        fillScene(c, sc, img);
+        RtQTable q;
+        q.normals = (const float4 *)c->raw[RT_SLOT_VORONOI_NORMALS].p;
+        q.centres = (const float4 *)c->raw[RT_SLOT_VORONOI_CENTRES].p;
+        q.qt = (float *)c->raw[RT_SLOT_QTABLE].p;
+        q.visits = (int *)c->raw[RT_SLOT_QVISITS].p;
+        q.numNormals = (int)std::min<size_t>(c->raw[RT_SLOT_VORONOI_NORMALS].bytes / 16, 0x7FFFFFFF);
+        q.numCentres = (int)std::min<size_t>(c->raw[RT_SLOT_VORONOI_CENTRES].bytes / 16, 0x7FFFFFFF);
+        q.numQ = (int)std::min<size_t>(c->raw[RT_SLOT_QTABLE].bytes / 4, 0x7FFFFFFF);
+        q.numVisits = (int)std::min<size_t>(c->raw[RT_SLOT_QVISITS].bytes / 4, 0x7FFFFFFF);
+        q.numPoints = p->numPoints;
+        q.maxTheta = p->maxTheta;
+        q.maxPhi = p->maxPhi;
+        for (int k = 0; k < n; ++k) { // the table is shared mutable state: one dispatch after the other
+            SpanGuard span(c, TK_TRACE), span2(c, RT_TIME_PER_PIXEL);
+            hipError_t e = rtLaunchTrace3RL(sc, q, img, params[k], r, (RtCountersDev *)c->counters.p, c->stream);
+            span2.end();
+            span.end();
+            if (e != hipSuccess) return hipFail(c, e, "trace3 RL launch");
+        }
         return RT_OK;
     }
     case RT_KERNEL_TRACE: case RT_KERNEL_TRACE1: case RT_KERNEL_TRACE2: {

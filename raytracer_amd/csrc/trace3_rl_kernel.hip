@@ -1,0 +1,283 @@
+// trace3_rl_kernel.hip — the reference's Q-table guided entry point, traceRL (reference
+// src/shaders/trace3.cs:695-791) with src/shaders/qtablehelper.glsl, as a gfx950 kernel.
+//
+// The reference's main() never calls traceRL (trace3.cs:807 calls trace); it is reachable here as
+// RT_KERNEL_TRACE3_RL.  One lane = one pixel-path, as in trace3_kernel.hip, sharing its traversal.
+//
+// Shared state.  Every path reads and updates one Q-table (Q[obj][cell][theta][phi] floats) and one visit
+// count per cell.  The reference does both without atomics from all invocations at once, so its frames depend
+// on the execution order and concurrent updates of a cell can be lost.  Here
+//   * the visit count is advanced with one atomic add, whose return value gives this update's
+//     alpha = 1 / (1 + visits);
+//   * Q <- (1 - alpha) Q + alpha u is applied with a compare-and-swap loop on the float's bits,
+// so every update is applied exactly once and a dispatch with a single path (the order-free case the parity
+// tests pin against the reference) evolves the table exactly as the reference does.  Vector atomics only.
+#include "trace3_device.h"
+
+#include "trace3_rl.h"
+
+namespace {
+
+// float -> int as the reference's oracle platform converts (cvttps2dq): INT_MIN when out of range / NaN
+__device__ __forceinline__ int f2i(float x) {
+    return (x >= -2147483648.0f && x < 2147483648.0f) ? (int)x : (int)0x80000000u;
+}
+// Buffer addressing of the oracle platform: out-of-range reads give 0, out-of-range writes are dropped, and the
+// byte offset index * stride is formed in 32 bits (it wraps) before the range check.  An index of INT_MIN + k
+// (what int(NaN) + k gives, e.g. findIndex with |ctheta| > 1) therefore addresses element k of a 4-byte array.
+__device__ __forceinline__ int wrapIndex(int i, unsigned stride, int count) {
+    const unsigned off = (unsigned)i * stride, e = off / stride;
+    return (e < (unsigned)count && off % stride == 0) ? (int)e : -1;
+}
+__device__ __forceinline__ f3 qNormal(const RtQTable &q, int i) {
+    i = wrapIndex(i, 16u, q.numNormals);
+    return i >= 0 ? xyz(q.normals[i]) : F3(0, 0, 0);
+}
+__device__ __forceinline__ f3 qCentre(const RtQTable &q, int i) {
+    i = wrapIndex(i, 16u, q.numCentres);
+    return i >= 0 ? xyz(q.centres[i]) : F3(0, 0, 0);
+}
+__device__ __forceinline__ float qRead(const RtQTable &q, int i) {
+    i = wrapIndex(i, 4u, q.numQ);
+    if (i < 0) return 0.0f;
+    return __uint_as_float(__hip_atomic_load((unsigned *)(q.qt + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ int objIdOf(const RtScene &sc, int tridx) {
+    const RtTri128 *t = triPtr(sc, tridx);
+    return t ? t->objId : 0;
+}
+
+__device__ __forceinline__ float fastacos(float x) { // qtablehelper.glsl:81-94
+    const float negate = (x < 0) ? 1.0f : 0.0f;
+    x = fabsf(x);
+    float ret = -0.0187293f;
+    ret = ret * x;
+    ret = ret + 0.0742610f;
+    ret = ret * x;
+    ret = ret - 0.2121144f;
+    ret = ret * x;
+    ret = ret + 1.5707288f;
+    ret = ret * sqrtf(1.0f - x);
+    ret = ret - (2 * negate) * ret;
+    return negate * PI_F + ret;
+}
+// nearest_with_normal_space, qtablehelper.glsl:176-196
+__device__ __forceinline__ unsigned findCell(const RtQTable &q, f3 pos, int objId, f3 normal) {
+    float nearest = 10000.0f;
+    unsigned nearestIdx = 0;
+    const f3 nn = normalize(normal);
+    for (int i = 0; i < q.numPoints; ++i) {
+        const f3 nv = qNormal(q, objId * q.numPoints + i);
+        if (nv.x != 0.0f || nv.y != 0.0f || nv.z != 0.0f) {
+            if (dot(normalize(nv), nn) > 0.866f) {
+                const f3 d = qCentre(q, objId * q.numPoints + i) - pos;
+                const float len = sqrtf(dot(d, d));
+                if (len < nearest) { nearestIdx = (unsigned)i; nearest = len; }
+            }
+        }
+    }
+    return nearestIdx;
+}
+__device__ __forceinline__ float maxQ(const RtQTable &q, unsigned idx, int objId) { // qtablehelper.glsl:212-224
+    float mq = 0;
+    const int base = q.numPoints * q.maxTheta * q.maxPhi * objId + q.maxTheta * q.maxPhi * (int)idx;
+    for (int i = 0; i < q.maxTheta; ++i)
+        for (int j = 0; j < q.maxPhi; ++j) mq = fmaxf(mq, qRead(q, base + i * q.maxPhi + j));
+    return mq;
+}
+__device__ __forceinline__ f3 orthogonal(f3 v) { // qtablehelper.glsl:231-235
+    return fabsf(v.x) > fabsf(v.z) ? F3(-v.y, v.x, 0.0f) : F3(0.0f, -v.z, v.y);
+}
+__device__ __forceinline__ int findIndex(const RtQTable &q, unsigned idx, int objId, f3 dir, f3 n) { // :245-274
+    const f3 normdir = normalize(dir), nvec = normalize(n);
+    const f3 uvec = normalize(orthogonal(nvec)), vvec = normalize(cross(nvec, uvec));
+    const float np = dot(nvec, normdir);
+    const int u = f2i(np * (float)q.maxTheta);
+    const float up = dot(uvec, normdir), vp = dot(vvec, normdir);
+    const float ctheta = up / sqrtf(1 - np * np);
+    const float theta = (vp > 0) ? fastacos(ctheta) : TWO_PI_F - fastacos(ctheta);
+    const int v = f2i((theta / TWO_PI_F) * (float)q.maxPhi);
+    const int base = q.numPoints * q.maxTheta * q.maxPhi * objId + q.maxTheta * q.maxPhi * (int)idx;
+    return (int)((unsigned)base + (unsigned)u * (unsigned)q.maxPhi + (unsigned)v);
+}
+// updateQtable, qtablehelper.glsl:286-318
+__device__ __forceinline__ int updateQtable(const RtScene &sc, const RtQTable &q, const Surface &oSI, const Surface &hSI,
+                                            f3 dir, float lastAttenuation, int prevIdx, unsigned &updates) {
+    const int oObj = objIdOf(sc, oSI.tridx), hObj = objIdOf(sc, hSI.tridx);
+    const unsigned idxPrev = prevIdx >= 0 ? (unsigned)prevIdx : findCell(q, oSI.point, oObj, oSI.normal);
+    const unsigned idxCurr = findCell(q, hSI.point, hObj, hSI.normal);
+    float update;
+    const RtMtl hm = fetchMtl(sc, hSI.matidx);
+    if (hm.emitter) {
+        const f3 ke = ld3(hm.Ke);
+        update = fminf(fmaxf(sqrtf(dot(ke, ke)), 0.0f), 1.0f);
+    } else {
+        update = lastAttenuation * maxQ(q, idxCurr, hObj);
+    }
+    const int idxQ = findIndex(q, idxPrev, oObj, -dir, oSI.normal);
+    const int vi = wrapIndex(q.numPoints * oObj + (int)idxPrev, 4u, q.numVisits);
+    int seen = 0;
+    if (vi >= 0) seen = atomicAdd(q.visits + vi, 1);
+    const float alpha = 1.0f / (1.0f + (float)seen);
+    const int qi = wrapIndex(idxQ, 4u, q.numQ);
+    if (qi >= 0) {
+        unsigned *addr = (unsigned *)(q.qt + qi);
+        unsigned old = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            const float nv = (1 - alpha) * __uint_as_float(old) + alpha * update;
+            const unsigned prev = atomicCAS(addr, old, __float_as_uint(nv));
+            if (prev == old) break;
+            old = prev;
+        }
+    }
+    ++updates;
+    return (int)idxCurr;
+}
+// sampleScatteringDir (:399-419) with sampleCdf (:328-354), uniformSamplePatch (:378-389), aroundv (:362-369)
+__device__ __forceinline__ f3 sampleScatteringDir(const RtScene &sc, const RtQTable &q, const Surface &SI, int QIdx,
+                                                  f3 rnd3, float &outpdf) {
+    const int obj = objIdOf(sc, SI.tridx);
+    const unsigned idx = QIdx >= 0 ? (unsigned)QIdx : findCell(q, SI.point, obj, SI.normal);
+    const int base = q.numPoints * q.maxPhi * q.maxTheta * obj + q.maxPhi * q.maxTheta * (int)idx;
+    float cdf = 0, den = 0, pdf = 0;
+    int pj = 0, pk = 0;
+    for (int j = 0; j < q.maxTheta; ++j)
+        for (int k = 0; k < q.maxPhi; ++k) den += qRead(q, base + j * q.maxPhi + k);
+    bool done = false;
+    float lastE = 0;
+    int lastJ = 0, lastK = 0;
+    for (int j = 0; j < q.maxTheta && !done; ++j)
+        for (int k = 0; k < q.maxPhi; ++k) {
+            const float e = qRead(q, base + j * q.maxPhi + k);
+            cdf += e;
+            if (e > 0) { lastE = e; lastJ = j; lastK = k; }
+            if (cdf / den >= rnd3.x) {
+                pdf = e / den;
+                pj = j; pk = k;
+                done = true;
+                break;
+            }
+        }
+    // Running off the end is impossible when the two passes read the same values (cdf ends at den exactly); it
+    // happens only when another path changed the row between the passes.  Take the last positive entry then,
+    // so that a concurrent update cannot produce a zero pdf (and from it a non-finite Q value for everyone).
+    if (!done && den > 0 && lastE > 0) { pdf = lastE / den; pj = lastJ; pk = lastK; }
+    const int nu = pk, nv = pj;
+    const float u = ((float)nu + rnd3.y) / (float)q.maxPhi, v = ((float)nv + rnd3.z) / (float)q.maxTheta;
+    const f3 d = F3(cosf(TWO_PI_F * v) * sqrtf(1 - u * u), sinf(TWO_PI_F * v) * sqrtf(1 - u * u), u);
+    const f3 nvec = normalize(SI.normal), uvec = normalize(orthogonal(nvec)), vvec = normalize(cross(nvec, uvec));
+    outpdf = ((pdf * (float)q.maxPhi) * (float)q.maxTheta) / TWO_PI_F;
+    return normalize((uvec * d.x + vvec * d.y) + nvec * d.z);
+}
+
+__global__ __launch_bounds__(256) void rt_trace3_rl_kernel(RtScene sc, RtQTable q, RtImages img, rt_trace_params p,
+                                                           rt_rect tile, int tilesX, RtCountersDev *counters) {
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx = (lane & 7) + 8 * (wave & 1), ly = (lane >> 3) + 8 * (wave >> 1);
+    const int x = tile.x0 + (t % tilesX) * 16 + lx, y = tile.y0 + (t / tilesX) * 16 + ly;
+    const bool active = x < tile.x1 && y < tile.y1;
+
+    PathCtx c;
+    c.px = x;
+    c.py = y;
+    c.time = p.time;
+    c.seed = 0;
+    c.oob0 = p.oobSeeds[0];
+    c.oob1 = p.oobSeeds[1];
+    c.oob2 = p.oobSeeds[2];
+    c.maxFollows = p.maxFollows > 0 ? p.maxFollows : 1000;
+    c.rays = c.visits = c.tests = c.shaded = 0;
+    c.lastIterations = 0;
+    unsigned updates = 0, primaryVisits = 0, primaryTests = 0;
+
+    if (active) {
+        const int W = img.width, H = img.height;
+        const size_t pix = (size_t)y * W + x;
+        const float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
+        f3 dir = normalize(mix(mix(ld3(p.ray00), ld3(p.ray01), pyf), mix(ld3(p.ray10), ld3(p.ray11), pyf), pxf));
+        f3 invdir = rcp3(dir);
+        f3 origin = ld3(p.eye);
+        f3 L = F3(0, 0, 0), beta = F3(1, 1, 1);
+        const f3 SKY = F3(0.89f, 0.96f, 1.00f);
+        int prevQIdx = -1;
+        Surface prevSI;
+        prevSI.tridx = -1; prevSI.matidx = 0; prevSI.normal = prevSI.point = F3(0, 0, 0);
+        for (int bounces = 0;; ++bounces) {
+            Surface SI;
+            intersectGeometry(sc, c, origin, dir, invdir, SI);
+            const bool found = SI.tridx != -1;
+            bool isAreaLight = false;
+            const RtMtl m = fetchMtl(sc, SI.matidx);
+            if (bounces == 0) { // write(), trace3.cs:357-361
+                const f3 n = found ? SI.normal : F3(0, 0, 0), qq = found ? SI.point : F3(0, 0, 0);
+                img.normal[pix] = snorm8(n.x) | (snorm8(n.y) << 8) | (snorm8(n.z) << 16);
+                img.pos[pix] = make_uint2(pack_half2_rtz(qq.x, qq.y), pack_half2_rtz(qq.z, 1.0f));
+                primaryVisits = c.visits;
+                primaryTests = c.tests;
+                if (p.flags & RT_FLAG_AUX) {
+                    img.tridx[pix] = SI.tridx;
+                    img.visits[pix] = c.lastIterations;
+                }
+            }
+            if (found) {
+                if (m.emitter) {
+                    if (L.x != L.x || L.y != L.y || L.z != L.z) { L = F3(1.0f, 0.0f, 1.0f); break; } // ERROR_COLOR
+                    L = L + (beta * ld3(m.Ke)) * 30.0f;
+                    isAreaLight = true;
+                }
+            } else {
+                L = L + beta * SKY;
+            }
+            if (bounces > 0)
+                prevQIdx = updateQtable(sc, q, prevSI, SI, dir, fmaxf(beta.x, fmaxf(beta.y, beta.z)), prevQIdx, updates);
+            if (!found || bounces >= p.maxBounces || isAreaLight) break;
+
+            origin = SI.point + SI.normal * EPSILON_F;
+            const f3 sample_rand = randvec3(c, bounces);
+            float pdf;
+            const f3 wi = sampleScatteringDir(sc, q, SI, prevQIdx, sample_rand, pdf); // sampleOutDirRL, :609-616
+            const f3 f = brdfSpecular(m.Ns, wi, -dir, SI.normal) * SPECULARITY + brdfDiffuse(ld3(m.Kd)) * (1.0f - SPECULARITY);
+            beta = beta * ((f * dot(normalize(SI.normal), normalize(wi))) / pdf);
+            dir = wi;
+            invdir = rcp3(wi);
+            const float rr_rand = randfloat(c, bounces);
+            const float rrbetamax = fmaxf(beta.x, fmaxf(beta.y, beta.z));
+            if (bounces > 3) {
+                const float qq = fmaxf(0.05f, 1 - rrbetamax);
+                if (rr_rand < qq) break;
+                beta = beta / (1.0f - qq);
+            }
+            prevSI = SI;
+        }
+        f3 old = F3(0, 0, 0);
+        if (p.blendFactor > 0.0f) {
+            const float4 o = img.color[pix];
+            old = F3(o.x, o.y, o.z);
+        }
+        const f3 fin = mix(L, old, p.blendFactor);
+        img.color[pix] = make_float4(fin.x, fin.y, fin.z, 1.0f);
+        if (p.flags & RT_FLAG_PIXEL_STATS) img.stats[pix] = make_int4((int)c.rays, (int)c.visits, (int)c.tests, (int)updates);
+    }
+    if (!(p.flags & RT_FLAG_NO_COUNTERS)) {
+        counters = counterShard(counters);
+        waveAdd(&counters->rays, c.rays);
+        waveAdd(&counters->node_visits, c.visits);
+        waveAdd(&counters->tri_tests, c.tests);
+        waveAdd(&counters->shaded_hits, c.shaded);
+        waveAdd(&counters->paths, active ? 1u : 0u);
+        waveAdd(&counters->primary_visits, primaryVisits);
+        waveAdd(&counters->primary_tests, primaryTests);
+    }
+}
+
+} // namespace
+
+hipError_t rtLaunchTrace3RL(const RtScene &sc, const RtQTable &q, const RtImages &img, const rt_trace_params &p,
+                            const rt_rect &tile, RtCountersDev *counters, hipStream_t stream) {
+    const int tw = tile.x1 - tile.x0, th = tile.y1 - tile.y0;
+    if (tw <= 0 || th <= 0) return hipSuccess;
+    const int tilesX = (tw + 15) / 16, tilesY = (th + 15) / 16;
+    hipLaunchKernelGGL(rt_trace3_rl_kernel, dim3(tilesX * tilesY), dim3(256), 0, stream, sc, q, img, p, tile, tilesX, counters);
+    return hipGetLastError();
+}

@@ -63,7 +63,7 @@ class Timings(ctypes.Structure):
         return {n: (self.ms[i], int(self.launches[i])) for i, n in enumerate(TIME_NAMES) if self.launches[i]}
 
 
-EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_upload", "rt_set_table", "rt_resize",
+EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_upload", "rt_set_table", "rt_download", "rt_resize",
            "rt_clear", "rt_trace", "rt_trace_batch", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
            "rt_readback_rect_device", "rt_write_rect_device", "rt_write_image", "rt_image_pixel_bytes",
            "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
@@ -89,6 +89,7 @@ def lib():
         L.rt_set_stream.argtypes = [vp, vp]
         L.rt_upload.argtypes = [vp, i32, vp, sz]
         L.rt_set_table.argtypes = [vp, i32, vp, sz]
+        L.rt_download.argtypes = [vp, i32, vp, sz]
         L.rt_resize.argtypes = [vp, i32, i32]
         L.rt_clear.argtypes = [vp]
         L.rt_trace.argtypes = [vp, ctypes.POINTER(TraceParams), rp]
@@ -174,6 +175,11 @@ class Context:
         for slot in sorted(buffers):
             if buffers[slot] or slot <= 6:
                 self.upload(slot, buffers[slot])
+
+    def download(self, slot, dtype, count):
+        out = np.empty(count, dtype)
+        self._check(lib().rt_download(self._h, slot, out.ctypes.data, out.nbytes), f"rt_download({slot})")
+        return out
 
     def set_tables(self, tables):
         """tables: {"sobol" | "scramble" | "ranking" | "ltc1" | "ltc2": bytes} (the reference's res/*.data contents)."""

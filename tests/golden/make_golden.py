@@ -14,7 +14,8 @@ The fixtures are data (inputs + expected outputs); no reference source text is s
 
   * analytic_*.npz    : the reference's trace.cs / trace1.cs / trace2.cs on llvmpipe (trace1 / trace2 with the
     load-time portability patches listed in oracle/run_ref_shader.c).
-usage: python tests/golden/make_golden.py [--only trace|ids|filter|kat|semantics|camera|analytic]
+  * rl_sequence_*.npz : trace3.cs with main() calling its traceRL entry point, one path per dispatch.
+usage: python tests/golden/make_golden.py [--only trace|ids|filter|kat|semantics|camera|analytic|rl]
 """
 import argparse
 import hashlib
@@ -122,6 +123,41 @@ def gen_analytic():
         np.savez_compressed(path, color=r["color"], normal=r["normal"], pos=r["pos"].view(np.uint16),
                             tridx=r["tridx"].astype(np.int16), rays=rays, eye=eye, meta=json.dumps(meta))
         print("wrote", path, os.path.getsize(path), "ids", np.unique(r["tridx"]).tolist())
+
+
+def rl_sequence(wl, n, seed):
+    """n single-path dispatches: rays through random points of the reference camera's image plane."""
+    rng = np.random.default_rng(seed)
+    rays = hostlib.camera_rays(width=64, height=64, **wl.camera)
+    uv = rng.random((n, 2)).astype(np.float32)
+    one = np.float32(1)
+    d = ((rays[0] * (one - uv[:, 1:2]) + rays[1] * uv[:, 1:2]) * (one - uv[:, 0:1]) +
+         (rays[2] * (one - uv[:, 1:2]) + rays[3] * uv[:, 1:2]) * uv[:, 0:1]).astype(np.float32)
+    seq = np.zeros((n, 8), np.float32)
+    seq[:, 0:3] = wl.eye
+    seq[:, 3:6] = d
+    seq[:, 6] = np.float32(1.25) + np.float32(0.0625) * np.arange(n, dtype=np.float32)
+    return seq
+
+
+def gen_rl():
+    """traceRL (trace3.cs:695-791, dead in the reference's main): trace3.cs with main() calling traceRL, run one path
+    per dispatch on a 1x1 image so that the order of the (non-atomic) Q-table updates is defined."""
+    for name, n, mb, seed in (("room", 600, 5, 3), ("room", 200, 2, 4)):
+        wl = workloads.Workload(name, 1, 1, with_qtable=True)
+        seq = rl_sequence(wl, n, seed)
+        r = refrun.run(wl.buffers, 1, 1, np.tile(seq[0, 3:6], (4, 1)), wl.eye, spp=1, max_bounces=mb,
+                       num_emitters=wl.num_emitters, shader="trace3rl", seq=seq, instrument=False)
+        q0 = np.frombuffer(wl.buffers[9], np.float32)
+        changed = np.nonzero(r["qtable"].view(np.uint32) != q0.view(np.uint32))[0].astype(np.int32)
+        visited = np.nonzero(r["qvisits"])[0].astype(np.int32)
+        meta = dict(scene=name, n=n, max_bounces=mb, seed=seed, num_emitters=wl.num_emitters,
+                    buffers_sha256={str(s): sha(wl.buffers[s]) for s in (3, 4, 5, 6, 7, 8, 9, 10)})
+        path = os.path.join(OUT, f"rl_sequence_{name}_{n}_mb{mb}.npz")
+        np.savez_compressed(path, seq=seq, seqcolor=r["seqcolor"].reshape(n, 4), q_changed_idx=changed,
+                            q_changed_val=r["qtable"][changed], visits_idx=visited, visits_val=r["qvisits"][visited],
+                            meta=json.dumps(meta))
+        print("wrote", path, os.path.getsize(path), "updates", int(r["qvisits"].sum()), "cells", visited.size)
 
 
 def gen_filter():
@@ -254,7 +290,7 @@ def main():
     if not refrun.available():
         sys.exit("reference oracle unavailable: run `make ref` in the container that holds /root/reference")
     steps = dict(camera=gen_camera, semantics=gen_semantics, kat=gen_kat, trace=gen_trace, filter=gen_filter,
-                 ids=gen_ids, analytic=gen_analytic)
+                 ids=gen_ids, analytic=gen_analytic, rl=gen_rl)
     for k, fn in steps.items():
         if a.only in (None, k):
             fn()

@@ -56,3 +56,24 @@ def half_ulp_diff(a_bits, b_bits):
         u = u.astype(np.int32)
         return np.where(u & 0x8000, -(u & 0x7FFF), u & 0x7FFF)
     return np.abs(key(np.asarray(a_bits)) - key(np.asarray(b_bits)))
+
+
+def check_rl_sequence(g, wl, colors, qt, visits):
+    """Compare a run of single-path traceRL dispatches with a tests/golden/rl_sequence_*.npz fixture."""
+    n = g["seq"].shape[0]
+    want_visits = np.zeros_like(visits)
+    want_visits[g["visits_idx"]] = g["visits_val"]
+    assert np.array_equal(visits, want_visits)                      # integer state: bit-exact
+    q0 = np.frombuffer(wl.buffers[9], np.float32)
+    want_q = q0.copy()
+    want_q[g["q_changed_idx"]] = g["q_changed_val"]
+    untouched = np.ones(q0.size, bool)
+    untouched[g["q_changed_idx"]] = False
+    assert np.array_equal(qt[untouched].view(np.uint32), q0[untouched].view(np.uint32))
+    err = np.abs(qt - want_q) / np.maximum(np.abs(want_q), 1.0)
+    assert err.max() < 2e-3, float(err.max())
+    assert (qt.view(np.uint32) == want_q.view(np.uint32)).mean() > 0.99
+    ref = g["seqcolor"][:, :3].astype(np.float64)
+    got = np.asarray(colors)[:, :3].astype(np.float64)
+    rel = np.abs(got - ref) / np.maximum(np.abs(ref), RADIANCE_FLOOR)
+    assert (rel > RADIANCE_RTOL).any(axis=1).mean() <= 0.01, (n, float(rel.max()))
