@@ -52,6 +52,13 @@ int rth_scene_add_triangles(rth_scene *s, const void *records, size_t n);
 int rth_scene_add_material(rth_scene *s, const float Kd[3], float Ns, const float Ke[3]);
 /* Harness light for emitter-less scenes: emissive quad facing -y. */
 int rth_scene_add_quad_light(rth_scene *s, const float centre[3], float half_x, float half_z, const float Ke[3]);
+/* Synthetic large scenes (the reference has no instancing): replace the triangles added
+ * so far by nx*ny*nz randomly rotated copies on a jittered lattice, flattened into one list.  pitch = pitch_factor
+ * * largest bbox extent; copy (i,j,k) sits at pitch * ((i,j,k) + jitter * (u - 0.5)); random numbers from PCG32
+ * (XSH-RR 64/32, stream 54) seeded with `seed`.  Call before adding the light and before rth_scene_build. */
+int rth_scene_replicate_lattice(rth_scene *s, int nx, int ny, int nz, uint64_t seed, float pitch_factor, float jitter);
+/* n-th output (0-based) of that generator, for known-answer tests. */
+uint32_t rth_pcg32_nth(uint64_t seed, uint64_t stream, int n);
 /* QTable(numObjs).makeVoronoi(...) then BVHContainer(...) (reference src/main.cpp:38-40).
  * with_qtable = 0 skips the Voronoi/Q-table step (slots 7-10 then hold one zero record). */
 int rth_scene_build(rth_scene *s, int with_qtable, uint32_t qtable_seed);

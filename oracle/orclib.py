@@ -96,7 +96,11 @@ class Scene:
     """Keeps the four byte streams alive and exposes them as an orc_scene."""
 
     def __init__(self, buffers):
-        self._keep = [np.frombuffer(buffers.get(s, b"") or b"\0" * 128, dtype=np.uint8).copy() for s in (3, 4, 5, 6)]
+        def keep(b):  # numpy arrays are used in place (large synthetic scenes), bytes are copied
+            if isinstance(b, np.ndarray):
+                return b.view(np.uint8).reshape(-1) if b.size else np.zeros(128, np.uint8)
+            return np.frombuffer(b or b"\0" * 128, dtype=np.uint8).copy()
+        self._keep = [keep(buffers.get(s, b"")) for s in (3, 4, 5, 6)]
         sizes = [len(buffers.get(s, b"")) for s in (3, 4, 5, 6)]
         self.c = OrcScene(self._keep[0].ctypes.data, sizes[0] // 48, self._keep[1].ctypes.data, sizes[1] // 128,
                           self._keep[2].ctypes.data, sizes[2] // 32, self._keep[3].ctypes.data, sizes[3] // 128)

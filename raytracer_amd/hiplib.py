@@ -165,15 +165,22 @@ class Context:
             raise RtError(f"{what}: {r}: {lib().rt_last_error(self._h).decode()}")
 
     def upload(self, slot, data):
-        data = bytes(data)
-        buf = (ctypes.c_char * max(len(data), 1)).from_buffer_copy(data or b"\0")
-        self._check(lib().rt_upload(self._h, slot, buf, len(data)), f"rt_upload({slot})")
+        if isinstance(data, np.ndarray):  # no copy: multi-gigabyte streams of the synthetic scenes
+            arr = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+            n = arr.size
+            self._check(lib().rt_upload(self._h, slot, ctypes.c_void_p(arr.ctypes.data if n else 0) if n else
+                                        ctypes.c_void_p(0), n), f"rt_upload({slot})")
+        else:
+            data = bytes(data)
+            n = len(data)
+            buf = (ctypes.c_char * max(n, 1)).from_buffer_copy(data or b"\0")
+            self._check(lib().rt_upload(self._h, slot, buf, n), f"rt_upload({slot})")
         if slot == 6:
-            self.num_emitters = len(data) // 128
+            self.num_emitters = n // 128
 
     def upload_scene(self, buffers):
         for slot in sorted(buffers):
-            if buffers[slot] or slot <= 6:
+            if len(buffers[slot]) or slot <= 6:
                 self.upload(slot, buffers[slot])
 
     def download(self, slot, dtype, count):

@@ -9,6 +9,8 @@
 
 using rtm::vec3;
 
+uint32_t rt_pcg32_nth(uint64_t seed, uint64_t stream, int n); // scene.cpp
+
 struct rth_scene {
     ModelLoader loader;
     std::unique_ptr<QTable> qtable;
@@ -90,13 +92,24 @@ int rth_scene_add_quad_light(rth_scene *s, const float c[3], float hx, float hz,
     return 0;
 }
 
+int rth_scene_replicate_lattice(rth_scene *s, int nx, int ny, int nz, uint64_t seed, float pitch_factor, float jitter) {
+    if (!s || nx < 1 || ny < 1 || nz < 1 || !(pitch_factor > 0.0f) || jitter < 0.0f) return -1;
+    if (s->bvh) return -2;
+    if (s->loader.triangles.empty()) return -3;
+    if ((double)nx * ny * nz * (double)s->loader.triangles.size() > 2.0e9) return -4; // int32 triangle indices
+    s->loader.replicateLattice(nx, ny, nz, seed, pitch_factor, jitter);
+    return 0;
+}
+
+uint32_t rth_pcg32_nth(uint64_t seed, uint64_t stream, int n) { return rt_pcg32_nth(seed, stream, n); }
+
 int rth_scene_build(rth_scene *s, int with_qtable, uint32_t qtable_seed) {
     if (!s) return -1;
     if (s->loader.triangles.empty()) return -3;
     s->qtable.reset(new QTable(with_qtable ? s->loader.numObjs : 0));
     s->qtable->seed = qtable_seed;
     if (with_qtable) s->qtable->makeVoronoi(s->loader.triangles_per_obj);
-    s->bvh.reset(new BVHContainer(s->loader.triangles, s->loader.materialsVector, s->loader.emitters,
+    s->bvh.reset(new BVHContainer(&s->loader.triangles, s->loader.materialsVector, s->loader.emitters,
                                   s->qtable->normal_per_voronoi, s->qtable->voronoi_centres));
     return 0;
 }

@@ -94,7 +94,19 @@ BVHContainer::BVHContainer(std::vector<Triangle> triangles, std::vector<Material
                            std::vector<std::vector<vec3>> voronoi_centres)
     : emitters(std::move(emitters)), materials(std::move(materials)) {
     build(triangles);
+    finish(normals_per_voronoi, voronoi_centres);
+}
 
+BVHContainer::BVHContainer(const std::vector<Triangle> *triangles, std::vector<Material *> materials,
+                           std::vector<Triangle> emitters, const std::vector<std::vector<vec3>> &normals_per_voronoi,
+                           const std::vector<std::vector<vec3>> &voronoi_centres)
+    : emitters(std::move(emitters)), materials(std::move(materials)) {
+    build(*triangles);
+    finish(normals_per_voronoi, voronoi_centres);
+}
+
+void BVHContainer::finish(const std::vector<std::vector<vec3>> &normals_per_voronoi,
+                          const std::vector<std::vector<vec3>> &voronoi_centres) {
     // reference BVH.cpp:321-325
     for (Material *m : this->materials) {
         GPUMaterial g;
@@ -457,6 +469,77 @@ void ModelLoader::bounds(vec3 &lo, vec3 &hi) const {
             for (int a = 0; a < 3; ++a) {
                 lo[a] = std::min(lo[a], t.vertices[k][a]);
                 hi[a] = std::max(hi[a], t.vertices[k][a]);
+            }
+}
+
+namespace {
+struct Pcg32 { // PCG XSH-RR 64/32 (O'Neill), the generator of the pcg32 demo: srandom(seed, stream)
+    uint64_t state = 0, inc = 0;
+    Pcg32(uint64_t seed, uint64_t stream) {
+        inc = (stream << 1u) | 1u;
+        next();
+        state += seed;
+        next();
+    }
+    uint32_t next() {
+        const uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        const uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((-rot) & 31));
+    }
+    float unit() { return (float)(next() >> 8) * (1.0f / 16777216.0f); } // [0,1), 24 bits
+};
+} // namespace
+
+uint32_t rt_pcg32_nth(uint64_t seed, uint64_t stream, int n) {
+    Pcg32 g(seed, stream);
+    uint32_t v = 0;
+    for (int i = 0; i <= n; ++i) v = g.next();
+    return v;
+}
+
+void ModelLoader::replicateLattice(int nx, int ny, int nz, uint64_t seed, float pitchFactor, float jitter) {
+    if (nx < 1 || ny < 1 || nz < 1 || triangles.empty()) return;
+    const std::vector<Triangle> base = triangles;
+    vec3 lo, hi;
+    bounds(lo, hi);
+    const vec3 centre = (lo + hi) * 0.5f, ext = hi - lo;
+    const float pitch = pitchFactor * std::max(ext.x, std::max(ext.y, ext.z));
+    triangles.clear();
+    emitters.clear();
+    triangles.reserve((size_t)nx * ny * nz * base.size());
+    Pcg32 rng(seed, 54u);
+    const float TWO_PI = 6.28318530717958647692f;
+    for (int i = 0; i < nx; ++i)
+        for (int j = 0; j < ny; ++j)
+            for (int k = 0; k < nz; ++k) {
+                // uniformly random rotation (Shoemake's quaternion from three uniform numbers)
+                const float u1 = rng.unit(), u2 = rng.unit(), u3 = rng.unit();
+                const float a = std::sqrt(1.0f - u1), b = std::sqrt(u1);
+                const float qx = a * std::sin(TWO_PI * u2), qy = a * std::cos(TWO_PI * u2), qz = b * std::sin(TWO_PI * u3),
+                            qw = b * std::cos(TWO_PI * u3);
+                const float R[3][3] = {
+                    {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)},
+                    {2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)},
+                    {2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)}};
+                const float jx = rng.unit() - 0.5f, jy = rng.unit() - 0.5f, jz = rng.unit() - 0.5f;
+                (void)rng.next(); // seventh draw: reserved (keeps copies on 7-draw boundaries)
+                const vec3 offset(pitch * ((float)i + jitter * jx), pitch * ((float)j + jitter * jy),
+                                  pitch * ((float)k + jitter * jz));
+                auto rot = [&](const vec3 &v) {
+                    return vec3(R[0][0] * v.x + R[0][1] * v.y + R[0][2] * v.z, R[1][0] * v.x + R[1][1] * v.y + R[1][2] * v.z,
+                                R[2][0] * v.x + R[2][1] * v.y + R[2][2] * v.z);
+                };
+                for (const Triangle &t : base) {
+                    Triangle c = t;
+                    for (int v = 0; v < 3; ++v) {
+                        c.vertices[v] = rot(t.vertices[v] - centre) + centre + offset;
+                        c.normals[v] = rot(t.normals[v]);
+                    }
+                    triangles.push_back(c);
+                    if (materialsVector[c.materialIndex]->emitter) emitters.push_back(c);
+                }
             }
 }
 

@@ -88,6 +88,11 @@ public:
     BVHContainer(std::vector<Triangle> triangles, std::vector<Material *> materials, std::vector<Triangle> emitters,
                  std::vector<std::vector<rtm::vec3>> normals_per_voronoi,
                  std::vector<std::vector<rtm::vec3>> voronoi_centres);
+    // Not in the reference: the same construction without copying the triangle list (tens of millions of
+    // triangles in the synthetic scenes); `triangles` is only read during the call.
+    BVHContainer(const std::vector<Triangle> *triangles, std::vector<Material *> materials,
+                 std::vector<Triangle> emitters, const std::vector<std::vector<rtm::vec3>> &normals_per_voronoi,
+                 const std::vector<std::vector<rtm::vec3>> &voronoi_centres);
 
     // SSBO "names" of the reference become slots of the launcher (binding numbers of
     // reference Tracer.cpp:173-178); the byte streams themselves are kept here.
@@ -107,6 +112,8 @@ public:
 
 private:
     void build(const std::vector<Triangle> &tris);
+    void finish(const std::vector<std::vector<rtm::vec3>> &normals_per_voronoi,
+                const std::vector<std::vector<rtm::vec3>> &voronoi_centres);
     std::vector<Material *> materials;
 };
 
@@ -135,6 +142,13 @@ public:
     // Not in the reference: append an already-built triangle (synthetic scenes).
     void addTriangle(const Triangle &t);
     int addMaterial(const Material &m, const std::string &name);
+    // Not in the reference (which has no instancing): replace the triangles loaded so far by nx*ny*nz rotated,
+    // jittered copies of them on a lattice, flattened into one triangle list.
+    // Copy (i,j,k) is rotated about the mesh centre by a uniformly random rotation and moved to
+    // pitch * (i,j,k) + pitch * jitter * (u - 0.5), pitch = pitchFactor * largest bbox extent; the random numbers
+    // come from PCG32 (XSH-RR 64/32, stream 54) seeded with `seed`, seven draws per copy in i-major order.
+    // Per-object triangle lists (only used by the Q-table) are not kept for the copies.
+    void replicateLattice(int nx, int ny, int nz, uint64_t seed, float pitchFactor, float jitter);
     void bounds(rtm::vec3 &lo, rtm::vec3 &hi) const;
     int defaultMaterialIndex();
 

@@ -48,6 +48,10 @@ def lib():
         L.rth_scene_add_material.argtypes = [vp, fp, ctypes.c_float, fp]
         L.rth_scene_add_quad_light.argtypes = [vp, fp, ctypes.c_float, ctypes.c_float, fp]
         L.rth_scene_build.argtypes = [vp, ctypes.c_int, ctypes.c_uint32]
+        L.rth_scene_replicate_lattice.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
+                                                  ctypes.c_float, ctypes.c_float]
+        L.rth_pcg32_nth.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int]
+        L.rth_pcg32_nth.restype = ctypes.c_uint32
         L.rth_scene_get_info.argtypes = [vp, ctypes.POINTER(SceneInfo)]
         L.rth_scene_buffer.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
         L.rth_scene_triangle_order.argtypes = [vp, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_size_t)]
@@ -104,6 +108,12 @@ class Scene:
         centre = [(lo[0] + hi[0]) * 0.5, hi[1] + 0.1 * diag, (lo[2] + hi[2]) * 0.5]
         self.add_quad_light(centre, 0.25 * (hi[0] - lo[0]), 0.25 * (hi[2] - lo[2]), Ke)
 
+    def replicate_lattice(self, nx, ny, nz, seed=0x5EED, pitch_factor=1.5, jitter=0.5):
+        """Replace the triangles by nx*ny*nz rotated, jittered copies (SURVEY.md 8(d) config #5)."""
+        r = lib().rth_scene_replicate_lattice(self._h, nx, ny, nz, seed, pitch_factor, jitter)
+        if r < 0:
+            raise RuntimeError(f"rth_scene_replicate_lattice: {r}")
+
     def build(self, with_qtable=True, qtable_seed=0x5EED):
         r = lib().rth_scene_build(self._h, int(with_qtable), qtable_seed)
         if r < 0:
@@ -123,6 +133,16 @@ class Scene:
         if r < 0:
             raise RuntimeError(f"rth_scene_buffer({slot}): {r}")
         return ctypes.string_at(p, n.value) if n.value else b""
+
+    def buffer_view(self, slot):
+        """The same stream as a uint8 array that aliases the library's memory (no copy; valid until close())."""
+        p, n = ctypes.c_void_p(), ctypes.c_size_t()
+        r = lib().rth_scene_buffer(self._h, slot, ctypes.byref(p), ctypes.byref(n))
+        if r < 0:
+            raise RuntimeError(f"rth_scene_buffer({slot}): {r}")
+        if not n.value:
+            return np.zeros(0, np.uint8)
+        return np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n.value,))
 
     def nodes(self):
         return np.frombuffer(self.buffer(SLOT_NODES), dtype=NODE_DTYPE)

@@ -36,6 +36,37 @@ class Workload:
         return self.info.num_emitters
 
 
+class LatticeWorkload:
+    """suzanne replicated on an nx x ny x nz jittered lattice (37 x 37 x 38 = 52 022
+    copies = 50.36 M triangles at full size), random rotations, PCG32 seed 0x5EED, Kd 0.7, one emissive quad, flattened
+    into one triangle stream.  `buffers` are views of the host library's memory (no copies), so the object must
+    stay alive while they are in use."""
+
+    def __init__(self, width, height, nx=37, ny=37, nz=38, seed=0x5EED, base="suzanne.obj"):
+        self.name, self.width, self.height = f"lattice{nx}x{ny}x{nz}", width, height
+        base_scene = hostlib.Scene(assets.path(base))
+        base_scene.build(with_qtable=False)
+        tris = base_scene.triangles().copy()
+        base_scene.close()
+        self.scene = hostlib.Scene()
+        tris["mtlIndex"] = self.scene.add_material((0.7, 0.7, 0.7), 32.0, (0.0, 0.0, 0.0))
+        tris["objId"] = 0
+        self.scene.add_triangles(tris)
+        self.scene.replicate_lattice(nx, ny, nz, seed)
+        pre = self.scene.info()
+        self.camera = hostlib.auto_camera(pre)
+        self.scene.add_harness_light()
+        self.scene.build(with_qtable=False)
+        self.info = self.scene.info()
+        self.buffers = {s: self.scene.buffer_view(s) for s in (3, 4, 5, 6)}
+        self.rays = hostlib.camera_rays(width=width, height=height, **self.camera)
+        self.eye = np.array(self.camera["eye"], np.float32)
+
+    @property
+    def num_emitters(self):
+        return self.info.num_emitters
+
+
 # ---------------------------------------------------------------------------------------------
 # The analytic-scene kernels (reference trace.cs / trace1.cs / trace2.cs) have no scene buffers; their
 # inputs are the camera and, for trace1 / trace2, the reference's sample / look-up tables.

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""SURVEY.md 8(d) config #5 at full size: suzanne on a 37 x 37 x 38 lattice (52 022 copies, 50.36 M triangles,
+6.4 GB of 128-byte records), 3840x2160, 1 spp, maxBounces 4, traversal cap lifted.  The scene no longer fits any
+cache: this is the HBM / Infinity-Cache-bound regime of the traversal kernels.
+
+  python scripts/config5.py [--lattice 37x37x38] [--size 3840x2160] [--reps 3] [--crop 96] [--out gpurun_out/config5.json]
+
+Prints progress lines (the host-side build takes tens of seconds) and one JSON summary: build / upload times,
+ms per frame, Mrays/s, per-kernel times, algorithmic bytes of the extend kernel, and the parity of a crop of the
+frame against the CPU oracle (primary-hit triangle ids and node-visit counts bit-exact, radiance within tolerance)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lattice", default="37x37x38")
+    ap.add_argument("--size", default="3840x2160")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--crop", type=int, default=96)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "config5.json"))
+    a = ap.parse_args()
+    nx, ny, nz = (int(v) for v in a.lattice.lower().split("x"))
+    W, H = (int(v) for v in a.size.lower().split("x"))
+    from raytracer_amd import hiplib, workloads
+    NO_CAP = 1 << 30
+
+    def say(*args):
+        print(f"[{time.strftime('%H:%M:%S')}]", *args, flush=True)
+
+    t = time.time()
+    wl = workloads.LatticeWorkload(W, H, nx, ny, nz)
+    t_build = time.time() - t
+    say(f"built {wl.info.num_triangles} triangles, {wl.info.num_nodes} nodes, depth {wl.info.depth} in {t_build:.1f} s")
+
+    ctx = hiplib.Context(0)
+    t = time.time()
+    ctx.upload_scene(wl.buffers)
+    ctx.sync()
+    t_upload = time.time() - t
+    say(f"uploaded {sum(v.size for v in wl.buffers.values()) / 1e9:.2f} GB in {t_upload:.1f} s")
+    ctx.resize(W, H)
+
+    flags = hiplib.FLAG_AUX
+    res = {}
+    for mode, extra in (("wavefront", 0), ("per_pixel", hiplib.FLAG_PER_PIXEL_KERNEL)):
+        ms = []
+        for rep in range(a.reps + 1):
+            ctx.clear()
+            ctx.sync()
+            ctx.reset_counters()
+            ctx.profile(True)
+            ctx.timings(reset=True)
+            t = time.perf_counter()
+            ctx.trace_samples(wl.rays, wl.eye, spp=1, max_bounces=a.bounces, flags=flags | extra,
+                              num_emitters=wl.num_emitters, max_follows=NO_CAP)
+            ctx.sync()
+            dt = (time.perf_counter() - t) * 1e3
+            if rep:
+                ms.append(dt)
+            say(f"{mode} rep {rep}: {dt:.1f} ms")
+        c = ctx.counters()
+        tm = ctx.timings().as_dict()
+        med = float(np.median(ms))
+        res[mode] = dict(ms_per_frame=round(med, 2), mrays_per_s=round(c.rays / med / 1e3, 1), rays=int(c.rays),
+                         node_visits=int(c.node_visits), tri_tests=int(c.tri_tests), shaded_hits=int(c.shaded_hits),
+                         primary_node_visits=int(c.primary_node_visits), primary_tri_tests=int(c.primary_tri_tests),
+                         kernel_ms={k: (round(v[0], 3), v[1]) for k, v in tm.items()})
+        if mode == "wavefront" and "wf_extend" in tm:
+            sec_v, sec_t = c.node_visits - c.primary_node_visits, c.tri_tests - c.primary_tri_tests
+            alg = 48.0 * (sec_v + sec_t) + 48.0 * (c.rays - c.paths)
+            res[mode]["extend_algorithmic_GBps"] = round(alg / (tm["wf_extend"][0] * 1e-3) / 1e9, 1)
+            alg_p = 48.0 * (c.primary_node_visits + c.primary_tri_tests) + 28.0 * c.paths
+            res[mode]["primary_algorithmic_GBps"] = round(alg_p / (tm["wf_primary"][0] * 1e-3) / 1e9, 1)
+        if mode == "wavefront":
+            got = {k: ctx.readback(v) for k, v in dict(color=hiplib.IMAGE_COLOR, tridx=hiplib.IMAGE_TRIDX,
+                                                       visits=hiplib.IMAGE_VISITS, normal=hiplib.IMAGE_NORMAL,
+                                                       pos=hiplib.IMAGE_POSITION).items()}
+        else:
+            same = {k: bool(np.array_equal(ctx.readback(v).view(np.uint8), got[k].view(np.uint8)))
+                    for k, v in dict(color=hiplib.IMAGE_COLOR, tridx=hiplib.IMAGE_TRIDX, visits=hiplib.IMAGE_VISITS).items()}
+            res["schedules_bit_identical"] = same
+
+    # parity of a crop against the CPU oracle (tests/ infrastructure; the crop is placed where geometry is)
+    from oracle import orclib
+    from tests.util import RADIANCE_FLOOR, RADIANCE_RTOL
+    hit = got["tridx"] >= 0
+    ys, xs = np.nonzero(hit)
+    cy, cx = int(np.median(ys)), int(np.median(xs))
+    n = a.crop
+    x0, y0 = max(0, min(W - n, cx - n // 2)), max(0, min(H - n, cy - n // 2))
+    rect = (x0, y0, x0 + n, y0 + n)
+    t = time.time()
+    ref = orclib.trace(orclib.Scene(wl.buffers), W, H, wl.rays, wl.eye, spp=1, max_bounces=a.bounces, rect=rect,
+                       max_follows=NO_CAP)
+    t_oracle = time.time() - t
+    sl = (slice(y0, y0 + n), slice(x0, x0 + n))
+    g, r = got["color"][sl][..., :3].astype(np.float64), ref["color"][sl][..., :3].astype(np.float64)
+    rel = np.abs(g - r) / np.maximum(np.abs(r), RADIANCE_FLOOR)
+    crop_rays = int(ref["stats_sum"][sl][..., 0].sum())
+    res["parity_crop"] = dict(rect=rect, hit_fraction=float(hit[sl].mean()),
+                              tridx_equal=bool(np.array_equal(got["tridx"][sl], ref["tridx"][sl])),
+                              visits_equal=bool(np.array_equal(got["visits"][sl], ref["visits"][sl])),
+                              normal_equal=bool(np.array_equal(got["normal"][sl], ref["normal"][sl])),
+                              pos_equal=bool(np.array_equal(got["pos"][sl].view(np.uint16), ref["pos"][sl].view(np.uint16))),
+                              radiance_outlier_fraction=float((rel.max(-1) > RADIANCE_RTOL).mean()),
+                              max_visits=int(ref["visits"][sl].max()),
+                              oracle_seconds=round(t_oracle, 2),
+                              oracle_mrays_per_s=round(crop_rays / t_oracle / 1e6, 3),
+                              oracle_threads=int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))
+    out = dict(config=f"lattice {nx}x{ny}x{nz} of suzanne.obj, {W}x{H}, 1 spp, maxBounces {a.bounces}, MAX_FOLLOWS lifted",
+               triangles=int(wl.info.num_triangles), nodes=int(wl.info.num_nodes), depth=int(wl.info.depth),
+               triangle_stream_GB=round(wl.buffers[4].size / 1e9, 2), build_seconds=round(t_build, 1),
+               upload_seconds=round(t_upload, 1), frame_hit_fraction=float(hit.mean()), **res)
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    with open(a.out, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
