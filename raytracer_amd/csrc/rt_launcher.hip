@@ -66,6 +66,8 @@ struct rt_ctx {
     DevBuf wfState[8], wfRay[6], wfQueue[2], wfCounts, wfRadiance;
     size_t wfCapacity = 0, wfRadianceSlots = 0;
     int tuneRefillLanes = 64, tuneExtendBlocks = 4; // development knobs: RT_WF_REFILL, RT_WF_BLOCKS
+    int tuneRaysPerWave = 0, tuneCoop = 0;           // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
+    int tuneCacheNodes = 672;                        // RT_WF_CACHE_NODES: 26.9 KB + 12 KB of wave scratch per block, 4 blocks per CU
 
     DevBuf counters;
     bool profile = false;
@@ -255,6 +257,9 @@ int rt_create(int device_id, rt_ctx **out) {
     }
     c->stream = c->ownStream;
     if (const char *e = std::getenv("RT_WF_REFILL")) c->tuneRefillLanes = std::max(1, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("RT_WF_CACHE_NODES")) c->tuneCacheNodes = std::max(0, std::min(3800, std::atoi(e)));
+    if (const char *e = std::getenv("RT_WF_RAYS_PER_WAVE")) c->tuneRaysPerWave = std::max(0, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("RT_WF_COOP")) c->tuneCoop = std::atoi(e);
     if (const char *e = std::getenv("RT_WF_BLOCKS")) c->tuneExtendBlocks = std::max(1, std::min(8, std::atoi(e)));
     if (ensure(c, c->counters, sizeof(RtCountersDev) * RT_COUNTER_SHARDS) != RT_OK ||
         hipMemsetAsync(c->counters.p, 0, sizeof(RtCountersDev) * RT_COUNTER_SHARDS, c->stream) != hipSuccess) {
@@ -441,6 +446,7 @@ void fillScene(const rt_ctx *c, RtScene &sc, RtImages &img) {
     sc.numTris = c->numTris;
     sc.numMtls = c->numMtls;
     sc.numEmitters = c->emitters.p ? c->numEmitters : 0;
+    sc.cacheNodes = 0;
     img.color = (float4 *)c->color.p;
     img.normal = (uint32_t *)c->normal.p;
     img.pos = (uint2 *)c->pos.p;
@@ -563,6 +569,9 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         wp.batch = n;
         wp.refillLanes = c->tuneRefillLanes;
         wp.extendBlocksPerCU = c->tuneExtendBlocks;
+        wp.extendCacheNodes = c->tuneCacheNodes;
+        wp.extendRaysPerWave = c->tuneRaysPerWave;
+        wp.extendCoop = c->tuneCoop;
         for (int k = 0; k < n; ++k) {
             wp.s[k].time = params[k].time;
             wp.s[k].blendFactor = params[k].blendFactor;

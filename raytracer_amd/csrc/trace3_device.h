@@ -218,6 +218,33 @@ __device__ __forceinline__ void testLeaf(const float4 *__restrict__ tris48, int 
     }
 }
 
+// ---------------------------------------------------------------- node fetch
+// LDS copy of the first sc.cacheNodes nodes: 2*M box records (float4) followed by M leaf ranges (int2),
+// 40 bytes per node.  An LDS read costs ~64 cycles against several hundred for an L2 hit, and the node
+// walk is one long chain of dependent reads, so for the scenes whose whole node array fits (the named
+// scenes have 90..670 nodes) the chain gets several times shorter; for large scenes the cached prefix is
+// the top of the tree.  Beyond the prefix the box and the leaf range are requested together.
+extern __shared__ float4 rtLdsNodes[];
+
+__device__ __forceinline__ void fillNodeCache(const RtScene &sc) {
+    const int m = sc.cacheNodes;
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) rtLdsNodes[i] = sc.boxes[i];
+    int2 *leaves = reinterpret_cast<int2 *>(rtLdsNodes + 2 * m);
+    for (int i = threadIdx.x; i < m; i += blockDim.x) leaves[i] = sc.leaves[i];
+    __syncthreads();
+}
+__device__ __forceinline__ void loadNode(const RtScene &sc, int node, float4 &b0, float4 &b1, int2 &leaf) {
+    if (node < sc.cacheNodes) {
+        b0 = rtLdsNodes[2 * node];
+        b1 = rtLdsNodes[2 * node + 1];
+        leaf = reinterpret_cast<const int2 *>(rtLdsNodes + 2 * sc.cacheNodes)[node];
+    } else {
+        b0 = sc.boxes[2 * node];
+        b1 = sc.boxes[2 * node + 1];
+        leaf = sc.leaves[node];
+    }
+}
+
 // ---------------------------------------------------------------- traversal
 // intersectGeometry's loop (trace3.cs:226-269) + intersectTriangles (:172-186).
 // Returns false when the MAX_FOLLOWS abort was taken (trace3.cs:228-234).
@@ -244,7 +271,9 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
                 next = -1;
                 break;
             }
-            const float4 b0 = sc.boxes[2 * next], b1 = sc.boxes[2 * next + 1];
+            float4 b0, b1;
+            int2 leaf;
+            loadNode(sc, next, b0, b1, leaf);
             const int hitNext = __float_as_int(b0.w), missNext = __float_as_int(b1.w);
             // intersectBox, geometry.glsl:66-76
             const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
@@ -257,7 +286,6 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
             if (!boxHit || mint > nearest) {
                 next = missNext;
             } else {
-                const int2 leaf = sc.leaves[next];
                 leafFirst = leaf.x;
                 leafCount = leaf.y; // 0 for inner nodes: keep walking
                 next = hitNext;

@@ -15,6 +15,9 @@ struct WfParams {
     int maxBounces, numEmitters, maxFollows, flags, batch;
     int refillLanes;       // idle lanes of a wave that trigger a refill from the ray queue (64 = only when all are idle)
     int extendBlocksPerCU; // persistent 256-thread blocks per CU of the extend kernel
+    int extendCacheNodes;  // nodes the extend kernel keeps in LDS (40 bytes each, per block)
+    int extendRaysPerWave; // 0 = chosen per launch from the queue size; 8..64 forces it (development knob)
+    int extendCoop;        // > 0 forces cooperative leaf testing also for full waves (development knob)
     WfSample s[WF_MAX_BATCH];
 };
 

@@ -26,6 +26,8 @@
 #include "trace3_device.h"
 #include "wavefront.h"
 
+#include <algorithm>
+
 namespace {
 
 __device__ __forceinline__ int waveAppend(int *counter, bool want) {
@@ -288,6 +290,14 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
 // coalescing in the vector L1 costs more than the idle lanes did.  Inside, the walk is the same "while-while" as traverse() in trace3_device.h —
 // per ray, node visits and triangle tests happen in the reference's order — kept as resumable state.
 
+struct WaveShare { // phase-2 exchange area of one wave (3 KB)
+    int incl[64];
+    int first[64];
+    float4 ro[64]; // origin, w = nearest
+    float4 rd[64];
+    unsigned long long key[64];
+};
+
 __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams p, WfBuffers wf, int stage,
                                                            int refillLanes, RtCountersDev *counters) {
     const int n = min(wf.counts[stage], wf.capacity);
@@ -298,6 +308,20 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     const float4 *rayO = wf.rayO[stage & 1], *rayD = wf.rayD[stage & 1];
     const bool wantWork = (p.flags & RT_FLAG_PIXEL_STATS) != 0;
     int *cursor = &wf.counts[32 + stage];
+    // Rays per wave.  With fewer rays than ray slots on the chip (a sparse bounce: scene.obj has ~140 k secondary
+    // rays per launch for 262 144 slots) a wave takes only `raysPerWave` rays into its first lanes, so that the work
+    // is spread over all resident waves: the launch then lasts as long as the slowest of 8..32 rays instead of the
+    // slowest of 64, and each SIMD has several waves to hide memory latency with.  Such waves test their leaves
+    // cooperatively (phase 2 below), which keeps all 64 lanes busy there whatever the number of rays.
+    const int residentWaves = (int)gridDim.x * (int)(blockDim.x >> 6);
+    int raysPerWave = 64;
+    while (raysPerWave > 8 && (long long)(raysPerWave / 2) * residentWaves >= total) raysPerWave >>= 1;
+    if (p.extendRaysPerWave > 0) raysPerWave = p.extendRaysPerWave;
+    const bool coop = raysPerWave < 64 || p.extendCoop > 0;
+    const bool rayLane = lane < raysPerWave;
+    fillNodeCache(sc);
+    // per-wave scratch behind the node cache
+    WaveShare *ws = reinterpret_cast<WaveShare *>(rtLdsNodes + (sc.cacheNodes * 40 + 15) / 16) + (threadIdx.x >> 6);
 
     // per-lane ray state
     bool active = false;
@@ -312,14 +336,15 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     bool exhausted = total <= 0;
 
     for (;;) {
-        const unsigned long long idle = __ballot(!active);
-        if (!exhausted && (idle == ~0ull || __popcll(idle) >= refillLanes)) {
+        const unsigned long long idle = __ballot(!active && rayLane);
+        const unsigned long long laneMask = raysPerWave >= 64 ? ~0ull : ((1ull << raysPerWave) - 1ull);
+        if (!exhausted && (idle == laneMask || __popcll(idle) >= refillLanes)) {
             const int want = __popcll(idle);
             int base = 0;
             if (lane == 0) base = atomicAdd(cursor, want);
             base = __shfl(base, 0, 64);
             if (base + want >= total) exhausted = true;
-            if (!active) {
+            if (!active && rayLane) {
                 const int w = base + __popcll(idle & lanesBelow);
                 if (w < total) {
                     const int kind = w / n, j = w - kind * n;
@@ -360,7 +385,9 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 next = -1;
                 break;
             }
-            const float4 b0 = sc.boxes[2 * next], b1 = sc.boxes[2 * next + 1];
+            float4 b0, b1;
+            int2 leaf;
+            loadNode(sc, next, b0, b1, leaf);
             const int hitNext = __float_as_int(b0.w), missNext = __float_as_int(b1.w);
             const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
                         m1z = (b0.z - origin.z) * invdir.z;
@@ -372,16 +399,76 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             if (!boxHit || mint > nearest) {
                 next = missNext;
             } else {
-                const int2 leaf = sc.leaves[next];
                 leafFirst = leaf.x;
                 leafCount = leaf.y;
                 next = hitNext;
             }
         }
-        // phase 2: the leaf's triangles (geometry.glsl:31-51, trace3.cs:172-186)
+        // phase 2: the leaves' triangles (geometry.glsl:31-51, trace3.cs:172-186), shared out over the wave.
+        // Lanes hold leaves of 1..32 triangles (or none); testing "my leaf" lane by lane leaves most lanes idle
+        // (measured: 38 % of the lanes active on room.obj, 20 % on scene.obj, and the kernel is VALU-issue
+        // bound).  Instead the wave lists all (ray, triangle) pairs of its leaves, every lane tests one pair per
+        // round, and the closest hit per ray is reduced with an LDS 64-bit atomic min on (t, triangle index).
+        // That is the reference's result: it keeps the first triangle in index order among those with the
+        // smallest t below the ray's current nearest (strict `<`, trace3.cs:177).
+        if (coop) {
+            const int cnt = (active && leafCount > 0) ? leafCount : 0;
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += v;
+            }
+            const int totalTests = __shfl(incl, 63, 64);
+            if (totalTests > 0) {
+                ws->incl[lane] = incl;
+                ws->first[lane] = leafFirst - (incl - cnt); // triangle of pair g is first[owner] + g
+                ws->ro[lane] = make_float4(origin.x, origin.y, origin.z, nearest);
+                ws->rd[lane] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+                ws->key[lane] = ~0ull;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int base = 0; base < totalTests; base += 64) {
+                    const int g = base + lane;
+                    if (g < totalTests) {
+                        int o = 0; // number of lanes whose inclusive count is <= g = the pair's owner
+#pragma unroll
+                        for (int st = 32; st > 0; st >>= 1)
+                            if (ws->incl[o + st - 1] <= g) o += st;
+                        const int tri = ws->first[o] + g;
+                        const float4 ro = ws->ro[o], rd = ws->rd[o];
+                        const float4 a0 = sc.tris48[3 * tri], a1 = sc.tris48[3 * tri + 1], a2 = sc.tris48[3 * tri + 2];
+                        float tn = ro.w, tt = 0.0f, tu = 0.0f, tv = 0.0f;
+                        int th = -1;
+                        testTriangle(a0, a1, a2, tri, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), tn, th, tt, tu, tv);
+                        if (th >= 0) { // t >= 0 and t < the ray's nearest; -0.0 is keyed as +0.0
+                            const unsigned long long key =
+                                ((unsigned long long)__float_as_uint(tt + 0.0f) << 32) | (unsigned)tri;
+                            atomicMin(&ws->key[o], key);
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (cnt > 0) {
+                    const unsigned long long key = ws->key[lane];
+                    if (key != ~0ull) { // the owner repeats the winning test: same arithmetic, same t, u, v
+                        const int tri = (int)(unsigned)(key & 0xFFFFFFFFull);
+                        testTriangle(sc.tris48[3 * tri], sc.tris48[3 * tri + 1], sc.tris48[3 * tri + 2], tri, origin, dir,
+                                     nearest, hitTri, hitT, hitU, hitV);
+                    }
+                    tests += (unsigned)cnt;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
         if (active && leafCount > 0) {
-            testLeaf(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
-            tests += (unsigned)leafCount;
+            if (!coop) { // full waves: every lane tests its own leaf, four triangles per batch of loads
+                testLeaf(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+                tests += (unsigned)leafCount;
+            }
         } else if (active && next == -1) {
             // the walk is over: publish the closest hit and free the lane
             wf.rayHit[slot] = make_int4(hitTri, __float_as_int(hitT), __float_as_int(hitU), __float_as_int(hitV));
@@ -438,18 +525,23 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     const int ntiles = tilesX * tilesY * p.batch;
     const int nblocks = ((ntiles + 7) / 8) * 8;
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, true);
-    hipLaunchKernelGGL(rt_wf_primary_kernel, dim3(nblocks), dim3(256), 0, stream, sc, img, p, wf, tile, tilesX, tilesY,
+    RtScene scPlain = sc, scExtend = sc;
+    scPlain.cacheNodes = 0;
+    scExtend.cacheNodes = std::max(0, std::min(sc.numNodes, p.extendCacheNodes));
+    const size_t extendLds = (((size_t)scExtend.cacheNodes * 40 + 15) / 16) * 16 + 4 * sizeof(WaveShare);
+    hipLaunchKernelGGL(rt_wf_primary_kernel, dim3(nblocks), dim3(256), 0, stream, scPlain, img, p, wf, tile, tilesX, tilesY,
                        xcdRemap, counters);
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, false);
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
     const int logicBlocks = 256 * 4, extendBlocks = 256 * p.extendBlocksPerCU;
     for (int b = 0; b <= p.maxBounces; ++b) {
         if (prof) rtMarkKernel(prof, RT_TIME_WF_LOGIC, true);
-        hipLaunchKernelGGL(rt_wf_logic_kernel, dim3(logicBlocks), dim3(256), 0, stream, sc, img, p, wf, tile, b, counters);
+        hipLaunchKernelGGL(rt_wf_logic_kernel, dim3(logicBlocks), dim3(256), 0, stream, scPlain, img, p, wf, tile, b, counters);
         if (prof) rtMarkKernel(prof, RT_TIME_WF_LOGIC, false);
         if (b < p.maxBounces) {
             if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, true);
-            hipLaunchKernelGGL(rt_wf_extend_kernel, dim3(extendBlocks), dim3(256), 0, stream, sc, p, wf, b + 1, p.refillLanes, counters);
+            hipLaunchKernelGGL(rt_wf_extend_kernel, dim3(extendBlocks), dim3(256), extendLds, stream, scExtend, p, wf, b + 1,
+                               p.refillLanes, counters);
             if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, false);
         }
     }
