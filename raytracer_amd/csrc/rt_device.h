@@ -1,7 +1,12 @@
 // rt_device.h — device-side data layout and fp32 helpers shared by the gfx950 kernels.
 //
 // HBM layout (built by rt_upload from the reference's std430 streams, see rt_launcher.hip):
-//   boxes   float4[2*N]   node i → {min.xyz, bits(hitNext)}, {max.xyz, bits(missNext)}   32 B, 32-B aligned
+//   boxes   float4[2*N]   node i → {min.xyz, bits(w0)}, {max.xyz, bits(w1)}                 32 B, 32-B aligned
+//           packed form (every leaf has <= 32 triangles and the triangle stream < 2^26 records, true for any tree
+//           the reference's builder makes up to 67 M triangles): w0 = missNext; w1 = hitNext for an inner node,
+//           0x80000000 | (numTris-1) << 26 | firstTri for a leaf (whose hitNext equals its missNext), so that one
+//           32-byte read gives the box, both links and the leaf range;
+//           plain form (anything else): w0 = hitNext, w1 = missNext, leaf range from `leaves`
 //   leaves  int2[N]       node i → {firstTri, numTris}                                    8 B
 //   tris48  float4[3*T]   triangle j → {v0,0}, {v1-v0,0}, {v2-v0,0}                      48 B, 16-B aligned
 //   tris128 the reference's 128-B triangle records, untouched (normals, mtlIndex, ...)   shading only
@@ -55,6 +60,7 @@ struct RtScene {
     // launch by the launcher of a kernel that fills the cache, 0 otherwise.  Nodes are numbered breadth-first
     // (reference BVH.cpp:223-241), so a prefix of the node array is exactly the top levels every ray walks.
     int cacheNodes;
+    int packedLeaves; // boxes are in the packed form (see the layout above)
 };
 
 struct RtImages {

@@ -66,8 +66,9 @@ struct rt_ctx {
     DevBuf wfState[8], wfRay[6], wfQueue[2], wfCounts, wfRadiance;
     size_t wfCapacity = 0, wfRadianceSlots = 0;
     int tuneRefillLanes = 64, tuneExtendBlocks = 4; // development knobs: RT_WF_REFILL, RT_WF_BLOCKS
+    bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
     int tuneRaysPerWave = 0, tuneCoop = 0;           // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
-    int tuneCacheNodes = 672;                        // RT_WF_CACHE_NODES: 26.9 KB + 12 KB of wave scratch per block, 4 blocks per CU
+    int tuneCacheNodes = 768;                        // RT_WF_CACHE_NODES: 24 KB + 12 KB of wave scratch per block, 4 blocks per CU
 
     DevBuf counters;
     bool profile = false;
@@ -317,6 +318,18 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
         std::vector<float4> boxes(2 * n);
         std::vector<int2> leaves(n);
         long long maxEnd = 0;
+        int maxLeaf = 0;
+        bool leafLinksEqual = true;
+        for (size_t i = 0; i < n; ++i) { // can the leaf range share the record with the links? (rt_device.h)
+            const RtNode48 &s = src[i];
+            if (s.numTris > 0) {
+                maxLeaf = std::max(maxLeaf, s.numTris);
+                if (s.hitNext != s.missNext) leafLinksEqual = false;
+                if (s.firstTri >= 0 && (long long)s.firstTri + s.numTris > maxEnd) maxEnd = (long long)s.firstTri + s.numTris;
+            }
+        }
+        const bool packed = leafLinksEqual && maxLeaf <= 32 && maxEnd <= (1ll << 26);
+        maxEnd = 0;
         for (size_t i = 0; i < n; ++i) {
             const RtNode48 &s = src[i];
             if (s.hitNext < -1 || s.hitNext >= (long long)n || s.missNext < -1 || s.missNext >= (long long)n)
@@ -324,9 +337,14 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
             if (s.numTris < 0 || s.firstTri < 0)
                 return fail(c, RT_ECORRUPT, "rt_upload: negative triangle range at node " + std::to_string(i));
             if (s.numTris > 0 && (long long)s.firstTri + s.numTris > maxEnd) maxEnd = (long long)s.firstTri + s.numTris;
+            int w0 = s.hitNext, w1 = s.missNext;
+            if (packed) {
+                w0 = s.missNext;
+                w1 = s.numTris > 0 ? (int)(0x80000000u | ((unsigned)(s.numTris - 1) << 26) | (unsigned)s.firstTri) : s.hitNext;
+            }
             float hb, mb;
-            std::memcpy(&hb, &s.hitNext, 4);
-            std::memcpy(&mb, &s.missNext, 4);
+            std::memcpy(&hb, &w0, 4);
+            std::memcpy(&mb, &w1, 4);
             boxes[2 * i] = make_float4(s.min[0], s.min[1], s.min[2], hb);
             boxes[2 * i + 1] = make_float4(s.max[0], s.max[1], s.max[2], mb);
             leaves[i] = make_int2(s.firstTri, s.numTris);
@@ -336,6 +354,7 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
         if ((r = uploadTo(c, c->leaves, leaves.data(), leaves.size() * sizeof(int2)))) return r;
         c->numNodes = (int)n;
         c->maxTriEnd = (int)maxEnd;
+        c->packedLeaves = packed;
         return RT_OK;
     }
     case RT_SLOT_TRIANGLES: {
@@ -447,6 +466,7 @@ void fillScene(const rt_ctx *c, RtScene &sc, RtImages &img) {
     sc.numMtls = c->numMtls;
     sc.numEmitters = c->emitters.p ? c->numEmitters : 0;
     sc.cacheNodes = 0;
+    sc.packedLeaves = c->packedLeaves ? 1 : 0;
     img.color = (float4 *)c->color.p;
     img.normal = (uint32_t *)c->normal.p;
     img.pos = (uint2 *)c->pos.p;

@@ -175,33 +175,43 @@ __device__ __forceinline__ float randomTriangleAreaDirectionPDF(f3 p, const Ligh
 // ---------------------------------------------------------------- leaf test
 // intersectTriangle (geometry.glsl:31-51) on one {v0, e1, e2} record; e1, e2 were subtracted at upload
 // with the same fp32 operations.  Updates the closest hit with the strict `<` of trace3.cs:177.
+// EARLY_OUT = true leaves at the first failed condition, as the reference does: right for coherent waves (primary
+// rays: neighbouring pixels test the same triangles and fail the same condition together).  EARLY_OUT = false
+// evaluates all conditions without branches (same operations, same values) and only the rare accepted candidate
+// pays for the division: right for waves of unrelated rays, which run the whole sequence anyway (measured on
+// MI355X, room.obj 1080p: extend kernel 44.8 -> 43.0 ms without the branches, primary kernel 1.8 -> 2.4 ms).
+template <bool EARLY_OUT>
 __device__ __forceinline__ void testTriangle(const float4 a0, const float4 a1, const float4 a2, int i, f3 origin,
                                              f3 dir, float &nearest, int &hitTri, float &hitT, float &hitU,
                                              float &hitV) {
     const f3 v0 = xyz(a0), e1 = xyz(a1), e2 = xyz(a2);
     const f3 pvec = cross(dir, e2);
     const float det = dot(e1, pvec);
-    if (det < 0.0f) return;
+    if (EARLY_OUT && det < 0.0f) return;
     const f3 tvec = origin - v0;
     const float u = dot(tvec, pvec);
-    if (u < 0.0f || u > det) return;
+    if (EARLY_OUT && (u < 0.0f || u > det)) return;
     const f3 qvec = cross(tvec, e1);
     const float v = dot(dir, qvec);
-    if (v < 0.0f || (u + v) > det) return;
-    const float invDet = 1.0f / det;
-    const float t = dot(e2, qvec) * invDet;
-    if (t >= 0.0f && t < nearest) {
-        nearest = t;
-        hitT = t;
-        hitU = u * invDet;
-        hitV = v * invDet;
-        hitTri = i;
+    if (EARLY_OUT && (v < 0.0f || (u + v) > det)) return;
+    const bool inside = EARLY_OUT || (!(det < 0.0f) & !(u < 0.0f || u > det) & !(v < 0.0f || (u + v) > det));
+    if (inside) {
+        const float invDet = 1.0f / det;
+        const float t = dot(e2, qvec) * invDet;
+        if (t >= 0.0f && t < nearest) {
+            nearest = t;
+            hitT = t;
+            hitU = u * invDet;
+            hitV = v * invDet;
+            hitTri = i;
+        }
     }
 }
 
 // intersectTriangles (trace3.cs:172-186) over [first, end): triangles are tested strictly in index
 // order, four records (12 aligned 16-byte loads) are requested before the first of them is tested so
 // that the load latency of a leaf is paid once per four triangles instead of once per triangle.
+template <bool EARLY_OUT>
 __device__ __forceinline__ void testLeaf(const float4 *__restrict__ tris48, int first, int end, f3 origin, f3 dir,
                                          float &nearest, int &hitTri, float &hitT, float &hitU, float &hitV) {
     for (int i = first; i < end; i += 4) {
@@ -211,37 +221,49 @@ __device__ __forceinline__ void testLeaf(const float4 *__restrict__ tris48, int 
         const float4 b0 = tris48[3 * i1], b1 = tris48[3 * i1 + 1], b2 = tris48[3 * i1 + 2];
         const float4 c0 = tris48[3 * i2], c1 = tris48[3 * i2 + 1], c2 = tris48[3 * i2 + 2];
         const float4 d0 = tris48[3 * i3], d1 = tris48[3 * i3 + 1], d2 = tris48[3 * i3 + 2];
-        testTriangle(a0, a1, a2, i, origin, dir, nearest, hitTri, hitT, hitU, hitV);
-        if (i + 1 < end) testTriangle(b0, b1, b2, i + 1, origin, dir, nearest, hitTri, hitT, hitU, hitV);
-        if (i + 2 < end) testTriangle(c0, c1, c2, i + 2, origin, dir, nearest, hitTri, hitT, hitU, hitV);
-        if (i + 3 < end) testTriangle(d0, d1, d2, i + 3, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+        testTriangle<EARLY_OUT>(a0, a1, a2, i, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+        if (i + 1 < end) testTriangle<EARLY_OUT>(b0, b1, b2, i + 1, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+        if (i + 2 < end) testTriangle<EARLY_OUT>(c0, c1, c2, i + 2, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+        if (i + 3 < end) testTriangle<EARLY_OUT>(d0, d1, d2, i + 3, origin, dir, nearest, hitTri, hitT, hitU, hitV);
     }
 }
 
 // ---------------------------------------------------------------- node fetch
-// LDS copy of the first sc.cacheNodes nodes: 2*M box records (float4) followed by M leaf ranges (int2),
-// 40 bytes per node.  An LDS read costs ~64 cycles against several hundred for an L2 hit, and the node
-// walk is one long chain of dependent reads, so for the scenes whose whole node array fits (the named
-// scenes have 90..670 nodes) the chain gets several times shorter; for large scenes the cached prefix is
-// the top of the tree.  Beyond the prefix the box and the leaf range are requested together.
+// LDS copy of the first sc.cacheNodes box records (32 bytes per node; only used with the packed node form).
+// An LDS read costs ~64 cycles against several hundred for an L2 hit, and the node walk is one long chain
+// of dependent reads, so for the scenes whose whole node array fits (the named scenes have 90..670 nodes)
+// the chain gets several times shorter; for large scenes the cached prefix is the top of the tree.
 extern __shared__ float4 rtLdsNodes[];
 
 __device__ __forceinline__ void fillNodeCache(const RtScene &sc) {
     const int m = sc.cacheNodes;
     for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) rtLdsNodes[i] = sc.boxes[i];
-    int2 *leaves = reinterpret_cast<int2 *>(rtLdsNodes + 2 * m);
-    for (int i = threadIdx.x; i < m; i += blockDim.x) leaves[i] = sc.leaves[i];
     __syncthreads();
 }
-__device__ __forceinline__ void loadNode(const RtScene &sc, int node, float4 &b0, float4 &b1, int2 &leaf) {
+struct NodeLinks {
+    int hitNext, missNext, leafFirst, leafCount; // leafCount = 0 for an inner node
+};
+__device__ __forceinline__ void loadNode(const RtScene &sc, int node, float4 &b0, float4 &b1, NodeLinks &k) {
     if (node < sc.cacheNodes) {
         b0 = rtLdsNodes[2 * node];
         b1 = rtLdsNodes[2 * node + 1];
-        leaf = reinterpret_cast<const int2 *>(rtLdsNodes + 2 * sc.cacheNodes)[node];
     } else {
         b0 = sc.boxes[2 * node];
         b1 = sc.boxes[2 * node + 1];
-        leaf = sc.leaves[node];
+    }
+    const int w0 = __float_as_int(b0.w), w1 = __float_as_int(b1.w);
+    if (sc.packedLeaves) {
+        const bool leaf = w1 < 0;
+        k.missNext = w0;
+        k.hitNext = leaf ? w0 : w1;
+        k.leafFirst = w1 & 0x03FFFFFF;
+        k.leafCount = leaf ? ((w1 >> 26) & 31) + 1 : 0;
+    } else {
+        const int2 lr = sc.leaves[node];
+        k.hitNext = w0;
+        k.missNext = w1;
+        k.leafFirst = lr.x;
+        k.leafCount = lr.y;
     }
 }
 
@@ -272,9 +294,8 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
                 break;
             }
             float4 b0, b1;
-            int2 leaf;
-            loadNode(sc, next, b0, b1, leaf);
-            const int hitNext = __float_as_int(b0.w), missNext = __float_as_int(b1.w);
+            NodeLinks k;
+            loadNode(sc, next, b0, b1, k);
             // intersectBox, geometry.glsl:66-76
             const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
                         m1z = (b0.z - origin.z) * invdir.z;
@@ -284,15 +305,15 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
             const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
             const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f;
             if (!boxHit || mint > nearest) {
-                next = missNext;
+                next = k.missNext;
             } else {
-                leafFirst = leaf.x;
-                leafCount = leaf.y; // 0 for inner nodes: keep walking
-                next = hitNext;
+                leafFirst = k.leafFirst;
+                leafCount = k.leafCount; // 0 for inner nodes: keep walking
+                next = k.hitNext;
             }
         }
         if (leafCount <= 0) break;
-        testLeaf(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
+        testLeaf<true>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
         tests += (unsigned)leafCount;
     }
     c.lastIterations = iterations;

@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     const bool rayLane = lane < raysPerWave;
     fillNodeCache(sc);
     // per-wave scratch behind the node cache
-    WaveShare *ws = reinterpret_cast<WaveShare *>(rtLdsNodes + (sc.cacheNodes * 40 + 15) / 16) + (threadIdx.x >> 6);
+    WaveShare *ws = reinterpret_cast<WaveShare *>(rtLdsNodes + 2 * sc.cacheNodes) + (threadIdx.x >> 6);
 
     // per-lane ray state
     bool active = false;
@@ -386,9 +386,8 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 break;
             }
             float4 b0, b1;
-            int2 leaf;
-            loadNode(sc, next, b0, b1, leaf);
-            const int hitNext = __float_as_int(b0.w), missNext = __float_as_int(b1.w);
+            NodeLinks k;
+            loadNode(sc, next, b0, b1, k);
             const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
                         m1z = (b0.z - origin.z) * invdir.z;
             const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
@@ -397,11 +396,11 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
             const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f; // geometry.glsl:66-76
             if (!boxHit || mint > nearest) {
-                next = missNext;
+                next = k.missNext;
             } else {
-                leafFirst = leaf.x;
-                leafCount = leaf.y;
-                next = hitNext;
+                leafFirst = k.leafFirst;
+                leafCount = k.leafCount;
+                next = k.hitNext;
             }
         }
         // phase 2: the leaves' triangles (geometry.glsl:31-51, trace3.cs:172-186), shared out over the wave.
@@ -441,7 +440,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                         const float4 a0 = sc.tris48[3 * tri], a1 = sc.tris48[3 * tri + 1], a2 = sc.tris48[3 * tri + 2];
                         float tn = ro.w, tt = 0.0f, tu = 0.0f, tv = 0.0f;
                         int th = -1;
-                        testTriangle(a0, a1, a2, tri, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), tn, th, tt, tu, tv);
+                        testTriangle<false>(a0, a1, a2, tri, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), tn, th, tt, tu, tv);
                         if (th >= 0) { // t >= 0 and t < the ray's nearest; -0.0 is keyed as +0.0
                             const unsigned long long key =
                                 ((unsigned long long)__float_as_uint(tt + 0.0f) << 32) | (unsigned)tri;
@@ -456,7 +455,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                     const unsigned long long key = ws->key[lane];
                     if (key != ~0ull) { // the owner repeats the winning test: same arithmetic, same t, u, v
                         const int tri = (int)(unsigned)(key & 0xFFFFFFFFull);
-                        testTriangle(sc.tris48[3 * tri], sc.tris48[3 * tri + 1], sc.tris48[3 * tri + 2], tri, origin, dir,
+                        testTriangle<false>(sc.tris48[3 * tri], sc.tris48[3 * tri + 1], sc.tris48[3 * tri + 2], tri, origin, dir,
                                      nearest, hitTri, hitT, hitU, hitV);
                     }
                     tests += (unsigned)cnt;
@@ -466,7 +465,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         }
         if (active && leafCount > 0) {
             if (!coop) { // full waves: every lane tests its own leaf, four triangles per batch of loads
-                testLeaf(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+                testLeaf<false>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
                 tests += (unsigned)leafCount;
             }
         } else if (active && next == -1) {
@@ -527,8 +526,8 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, true);
     RtScene scPlain = sc, scExtend = sc;
     scPlain.cacheNodes = 0;
-    scExtend.cacheNodes = std::max(0, std::min(sc.numNodes, p.extendCacheNodes));
-    const size_t extendLds = (((size_t)scExtend.cacheNodes * 40 + 15) / 16) * 16 + 4 * sizeof(WaveShare);
+    scExtend.cacheNodes = sc.packedLeaves ? std::max(0, std::min(sc.numNodes, p.extendCacheNodes)) : 0;
+    const size_t extendLds = (size_t)scExtend.cacheNodes * 32 + 4 * sizeof(WaveShare);
     hipLaunchKernelGGL(rt_wf_primary_kernel, dim3(nblocks), dim3(256), 0, stream, scPlain, img, p, wf, tile, tilesX, tilesY,
                        xcdRemap, counters);
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, false);
