@@ -67,8 +67,8 @@ struct rt_ctx {
     size_t wfCapacity = 0, wfRadianceSlots = 0;
     int tuneRefillLanes = 64, tuneExtendBlocks = 4; // development knobs: RT_WF_REFILL, RT_WF_BLOCKS
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
-    int tuneRaysPerWave = 0, tuneCoop = 0;           // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
-    int tuneCacheNodes = 768;                        // RT_WF_CACHE_NODES: 24 KB + 12 KB of wave scratch per block, 4 blocks per CU
+    int tuneRaysPerWave = 0, tuneCoop = -1;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
+    int tuneCacheNodes = 640;                        // RT_WF_CACHE_NODES: 20 KB + 19 KB of wave scratch per block, 4 blocks per CU
 
     DevBuf counters;
     bool profile = false;
@@ -591,7 +591,10 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         wp.extendBlocksPerCU = c->tuneExtendBlocks;
         wp.extendCacheNodes = c->tuneCacheNodes;
         wp.extendRaysPerWave = c->tuneRaysPerWave;
-        wp.extendCoop = c->tuneCoop;
+        // full waves test their leaves cooperatively when the triangles do not fit the L2s (measured on MI355X: the
+        // coalesced triangle reads of that scheme win on the 1.7 M-triangle lattice, 3.66 -> 3.28 ms, and lose to
+        // lane-by-lane testing on L2-resident room.obj, 41.4 -> 48.9 ms)
+        wp.extendCoop = c->tuneCoop >= 0 ? c->tuneCoop : (hot > (size_t)3 * 1024 * 1024 ? 1 : 0);
         for (int k = 0; k < n; ++k) {
             wp.s[k].time = params[k].time;
             wp.s[k].blendFactor = params[k].blendFactor;

@@ -290,8 +290,8 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
 // coalescing in the vector L1 costs more than the idle lanes did.  Inside, the walk is the same "while-while" as traverse() in trace3_device.h —
 // per ray, node visits and triangle tests happen in the reference's order — kept as resumable state.
 
-struct WaveShare { // phase-2 exchange area of one wave (3 KB)
-    int incl[64];
+struct WaveShare { // phase-2 exchange area of one wave (4.75 KB)
+    unsigned char owner[2048]; // pair index -> lane that owns the ray (64 lanes x at most 32 triangles)
     int first[64];
     float4 ro[64]; // origin, w = nearest
     float4 rd[64];
@@ -317,7 +317,8 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     int raysPerWave = 64;
     while (raysPerWave > 8 && (long long)(raysPerWave / 2) * residentWaves >= total) raysPerWave >>= 1;
     if (p.extendRaysPerWave > 0) raysPerWave = p.extendRaysPerWave;
-    const bool coop = raysPerWave < 64 || p.extendCoop > 0;
+    if (!sc.packedLeaves) raysPerWave = 64; // the pair list below is sized for leaves of at most 32 triangles
+    const bool coop = sc.packedLeaves && (raysPerWave < 64 || p.extendCoop > 0);
     const bool rayLane = lane < raysPerWave;
     fillNodeCache(sc);
     // per-wave scratch behind the node cache
@@ -420,24 +421,38 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             }
             const int totalTests = __shfl(incl, 63, 64);
             if (totalTests > 0) {
-                ws->incl[lane] = incl;
-                ws->first[lane] = leafFirst - (incl - cnt); // triangle of pair g is first[owner] + g
+                const int excl = incl - cnt;
+                ws->first[lane] = leafFirst - excl; // triangle of pair g is first[owner] + g
                 ws->ro[lane] = make_float4(origin.x, origin.y, origin.z, nearest);
                 ws->rd[lane] = make_float4(dir.x, dir.y, dir.z, 0.0f);
                 ws->key[lane] = ~0ull;
+                for (int k = 0; k < cnt; ++k) ws->owner[excl + k] = (unsigned char)lane; // pair -> owning lane
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // rounds of 64 pairs; the triangle of the next round is requested before this round's is tested
+                int g = lane, o = 0, tri = 0;
+                float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
+                if (g < totalTests) {
+                    o = ws->owner[g];
+                    tri = ws->first[o] + g;
+                    a0 = sc.tris48[3 * tri];
+                    a1 = sc.tris48[3 * tri + 1];
+                    a2 = sc.tris48[3 * tri + 2];
+                }
                 for (int base = 0; base < totalTests; base += 64) {
-                    const int g = base + lane;
+                    const int gn = g + 64;
+                    int on = 0, trin = 0;
+                    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+                    if (gn < totalTests) {
+                        on = ws->owner[gn];
+                        trin = ws->first[on] + gn;
+                        n0 = sc.tris48[3 * trin];
+                        n1 = sc.tris48[3 * trin + 1];
+                        n2 = sc.tris48[3 * trin + 2];
+                    }
                     if (g < totalTests) {
-                        int o = 0; // number of lanes whose inclusive count is <= g = the pair's owner
-#pragma unroll
-                        for (int st = 32; st > 0; st >>= 1)
-                            if (ws->incl[o + st - 1] <= g) o += st;
-                        const int tri = ws->first[o] + g;
                         const float4 ro = ws->ro[o], rd = ws->rd[o];
-                        const float4 a0 = sc.tris48[3 * tri], a1 = sc.tris48[3 * tri + 1], a2 = sc.tris48[3 * tri + 2];
                         float tn = ro.w, tt = 0.0f, tu = 0.0f, tv = 0.0f;
                         int th = -1;
                         testTriangle<false>(a0, a1, a2, tri, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), tn, th, tt, tu, tv);
@@ -447,6 +462,8 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                             atomicMin(&ws->key[o], key);
                         }
                     }
+                    g = gn; o = on; tri = trin;
+                    a0 = n0; a1 = n1; a2 = n2;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -454,9 +471,9 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 if (cnt > 0) {
                     const unsigned long long key = ws->key[lane];
                     if (key != ~0ull) { // the owner repeats the winning test: same arithmetic, same t, u, v
-                        const int tri = (int)(unsigned)(key & 0xFFFFFFFFull);
-                        testTriangle<false>(sc.tris48[3 * tri], sc.tris48[3 * tri + 1], sc.tris48[3 * tri + 2], tri, origin, dir,
-                                     nearest, hitTri, hitT, hitU, hitV);
+                        const int wtri = (int)(unsigned)(key & 0xFFFFFFFFull);
+                        testTriangle<false>(sc.tris48[3 * wtri], sc.tris48[3 * wtri + 1], sc.tris48[3 * wtri + 2], wtri, origin,
+                                            dir, nearest, hitTri, hitT, hitU, hitV);
                     }
                     tests += (unsigned)cnt;
                 }
