@@ -496,12 +496,12 @@ __device__ __forceinline__ RtCountersDev *counterShard(RtCountersDev *base) {
     return base + ((blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) & (RT_COUNTER_SHARDS - 1));
 }
 __device__ __forceinline__ void waveAdd(unsigned long long *dst, unsigned v) {
-    unsigned long long s = v;
+    // per-lane counts of one launch are far below 2^26, so the wave's sum fits 32 bits
+    unsigned s = v;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, s);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(dst, (unsigned long long)s);
 }
-
 
 } // namespace
 

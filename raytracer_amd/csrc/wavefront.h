@@ -17,6 +17,8 @@ struct WfParams {
     int extendBlocksPerCU; // persistent 256-thread blocks per CU of the extend kernel
     int extendCacheNodes;  // nodes the extend kernel keeps in LDS (40 bytes each, per block)
     int extendRaysPerWave; // 0 = chosen per launch from the queue size; 8..64 forces it (development knob)
+    int extendFill;        // rays-per-wave rule: halve while (rays/2) * resident waves * extendFill >= queued rays
+    int extendChunk;       // most queue entries a wave takes with one atomic on the shared cursor
     int extendCoop;        // > 0 forces cooperative leaf testing also for full waves (development knob)
     WfSample s[WF_MAX_BATCH];
 };

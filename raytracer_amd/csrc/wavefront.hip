@@ -94,11 +94,31 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
     h.t = h.u = h.v = 0.0f;
     f3 dir = F3(0, 0, 0);
     const int W = img.width, H = img.height;
+    f3 invdir = F3(0, 0, 0);
+    bool entersScene = false;
     if (active) {
         // trace3.cs:805-807
         const float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
         dir = normalize(mix(mix(ld3(p.ray00), ld3(p.ray01), pyf), mix(ld3(p.ray10), ld3(p.ray11), pyf), pxf));
-        traverse(sc, c, ld3(p.eye), dir, rcp3(dir), h);
+        invdir = rcp3(dir);
+        // does this ray get past the root?  (the same box test the walk starts with)
+        const float4 b0 = sc.boxes[0], b1 = sc.boxes[1];
+        const f3 eye = ld3(p.eye);
+        const float m1x = (b0.x - eye.x) * invdir.x, m1y = (b0.y - eye.y) * invdir.y, m1z = (b0.z - eye.z) * invdir.z;
+        const float m2x = (b1.x - eye.x) * invdir.x, m2y = (b1.y - eye.y) * invdir.y, m2z = (b1.z - eye.z) * invdir.z;
+        const bool ltx = invdir.x < 0.0f, lty = invdir.y < 0.0f, ltz = invdir.z < 0.0f;
+        const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
+        const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
+        entersScene = maxt >= 0.0f && mint <= maxt * 1.00000024f;
+    }
+    // Only the tiles that see the scene's bounding box copy the top of the tree into LDS (a few per cent of the
+    // tiles for the named scenes under the survey's camera); the others finish after their one root test.
+    if (sc.cacheNodes > 0) {
+        if (__syncthreads_or(entersScene)) fillNodeCache(sc);
+        else sc.cacheNodes = 0;
+    }
+    if (active) {
+        traverse(sc, c, ld3(p.eye), dir, invdir, h);
         const size_t pix = (size_t)y * W + x;
         if (p.flags & RT_FLAG_AUX) {
             img.tridx[pix] = h.tridx;
@@ -131,10 +151,22 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
         wf.rayHit[r] = make_int4(h.tridx, __float_as_int(h.t), __float_as_int(h.u), __float_as_int(h.v));
         if (p.flags & RT_FLAG_PIXEL_STATS) wf.pathStats[slot] = make_int4((int)c.rays, (int)c.visits, (int)c.tests, 0);
     }
-    flushCounters(p, counters, c, active ? 1u : 0u);
-    if (!(p.flags & RT_FLAG_NO_COUNTERS)) {
-        waveAdd(&counterShard(counters)->primary_visits, c.visits);
-        waveAdd(&counterShard(counters)->primary_tests, c.tests);
+    if (!(p.flags & RT_FLAG_NO_COUNTERS)) { // one primary ray per active lane: three sums feed six counters
+        RtCountersDev *cs = counterShard(counters);
+        const unsigned long long act = __ballot(active);
+        unsigned v = c.visits, t = c.tests;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            v += __shfl_down(v, off, 64);
+            t += __shfl_down(t, off, 64);
+        }
+        if (lane == 0 && act) {
+            const unsigned long long n = (unsigned long long)__popcll(act);
+            atomicAdd(&cs->rays, n);
+            atomicAdd(&cs->paths, n);
+            if (v) { atomicAdd(&cs->node_visits, (unsigned long long)v); atomicAdd(&cs->primary_visits, (unsigned long long)v); }
+            if (t) { atomicAdd(&cs->tri_tests, (unsigned long long)t); atomicAdd(&cs->primary_tests, (unsigned long long)t); }
+        }
     }
 }
 
@@ -315,7 +347,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     // cooperatively (phase 2 below), which keeps all 64 lanes busy there whatever the number of rays.
     const int residentWaves = (int)gridDim.x * (int)(blockDim.x >> 6);
     int raysPerWave = 64;
-    while (raysPerWave > 8 && (long long)(raysPerWave / 2) * residentWaves >= total) raysPerWave >>= 1;
+    while (raysPerWave > 8 && (long long)(raysPerWave / 2) * residentWaves * p.extendFill >= total) raysPerWave >>= 1;
     if (p.extendRaysPerWave > 0) raysPerWave = p.extendRaysPerWave;
     if (!sc.packedLeaves) raysPerWave = 64; // the pair list below is sized for leaves of at most 32 triangles
     const bool coop = sc.packedLeaves && (raysPerWave < 64 || p.extendCoop > 0);
@@ -335,19 +367,31 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     // totals for the global counters
     unsigned cRays = 0, cVisits = 0, cTests = 0;
     bool exhausted = total <= 0;
+    // The queue cursor is one word shared by every wave of the launch, and atomics on one address retire at only
+    // ~90 per microsecond on this part, so a wave takes a chunk of the queue per atomic (several refills' worth)
+    // and hands it out to its lanes locally.  The chunk shrinks with the queue so that the tail stays balanced.
+    int chunk = (int)min((long long)p.extendChunk, (long long)total / ((long long)residentWaves * 4));
+    chunk = max(raysPerWave, chunk - chunk % raysPerWave);
+    int chunkNext = 0, chunkEnd = 0; // this wave's current piece of the queue: [chunkNext, chunkEnd)
 
     for (;;) {
         const unsigned long long idle = __ballot(!active && rayLane);
         const unsigned long long laneMask = raysPerWave >= 64 ? ~0ull : ((1ull << raysPerWave) - 1ull);
         if (!exhausted && (idle == laneMask || __popcll(idle) >= refillLanes)) {
-            const int want = __popcll(idle);
-            int base = 0;
-            if (lane == 0) base = atomicAdd(cursor, want);
-            base = __shfl(base, 0, 64);
-            if (base + want >= total) exhausted = true;
+            if (chunkNext >= chunkEnd) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(cursor, chunk);
+                chunkNext = __shfl(base, 0, 64);
+                chunkEnd = min(chunkNext + chunk, total);
+            }
+            const int want = min(__popcll(idle), max(chunkEnd - chunkNext, 0));
+            const int base = chunkNext;
+            chunkNext += __popcll(idle); // a chunk's remainder smaller than the idle lanes is handed out as it is
+            if (chunkNext >= chunkEnd && chunkEnd >= total) exhausted = true;
+            (void)want;
             if (!active && rayLane) {
                 const int w = base + __popcll(idle & lanesBelow);
-                if (w < total) {
+                if (w < chunkEnd) {
                     const int kind = w / n, j = w - kind * n;
                     slot = kind * cap + j;
                     const float4 ro = rayO[slot];
@@ -541,12 +585,13 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     const int ntiles = tilesX * tilesY * p.batch;
     const int nblocks = ((ntiles + 7) / 8) * 8;
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, true);
-    RtScene scPlain = sc, scExtend = sc;
+    RtScene scPlain = sc, scExtend = sc, scPrimary = sc;
     scPlain.cacheNodes = 0;
+    scPrimary.cacheNodes = sc.packedLeaves ? std::max(0, std::min(sc.numNodes, std::min(p.extendCacheNodes, 1024))) : 0;
     scExtend.cacheNodes = sc.packedLeaves ? std::max(0, std::min(sc.numNodes, p.extendCacheNodes)) : 0;
     const size_t extendLds = (size_t)scExtend.cacheNodes * 32 + 4 * sizeof(WaveShare);
-    hipLaunchKernelGGL(rt_wf_primary_kernel, dim3(nblocks), dim3(256), 0, stream, scPlain, img, p, wf, tile, tilesX, tilesY,
-                       xcdRemap, counters);
+    hipLaunchKernelGGL(rt_wf_primary_kernel, dim3(nblocks), dim3(256), (size_t)scPrimary.cacheNodes * 32, stream, scPrimary,
+                       img, p, wf, tile, tilesX, tilesY, xcdRemap, counters);
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, false);
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
     const int logicBlocks = 256 * 4, extendBlocks = 256 * p.extendBlocksPerCU;
