@@ -80,7 +80,13 @@ enum rt_flags {
     RT_FLAG_AUX = 1,       /* also write primary-hit triangle index + node-visit count images */
     RT_FLAG_PIXEL_STATS = 2, /* also write per-pixel (traversals, node visits, triangle tests, 0)  */
     RT_FLAG_NO_COUNTERS = 4, /* skip the global ray / visit / test counters                      */
-    RT_FLAG_PER_PIXEL_KERNEL = 8 /* run the one-lane-per-path kernel instead of the wavefront pipeline (same results) */
+    RT_FLAG_PER_PIXEL_KERNEL = 8, /* run the one-lane-per-path kernel instead of the wavefront pipeline (same results) */
+    /* NOT the reference's algorithm; off by default.  visible() (reference trace3.cs:487-497) asks whether the
+     * closest hit along a shadow ray is the sampled light triangle.  With this flag the light triangle is tested
+     * first: a ray that misses it is never cast, the others stop at the first hit nearer than the light
+     * (any-hit, reference SURVEY 8(f) rank 4).  Same answer except when another triangle is hit at exactly the
+     * light's distance; the ray / visit / test counters then count the work actually done. */
+    RT_FLAG_FAST_SHADOWS = 16
 };
 
 typedef struct rt_rect {

@@ -173,6 +173,18 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
 // ------------------------------------------------------------------------------------------ logic
 #define WF_FLAG_PENDING 1 // the path has shadow rays of the previous bounce to resolve
 #define WF_FLAG_ENDED 2   // terminated by the roulette: resolve, then finish (no continuation ray was cast)
+#define WF_HIT_UNBLOCKED (-2) // RT_FLAG_FAST_SHADOWS: a bounded shadow ray that found nothing nearer than its light
+
+// Distance at which a ray meets the front of the light triangle (geometry.glsl:31-51 on the emitter record), or a
+// negative value: RT_FLAG_FAST_SHADOWS only.
+__device__ __forceinline__ float lightDistance(const LightTri &t, f3 origin, f3 dir) {
+    float nearest = __builtin_inff(), ht = 0.0f, hu = 0.0f, hv = 0.0f;
+    int hi = -1;
+    const f3 e1 = t.v1 - t.v0, e2 = t.v2 - t.v0;
+    testTriangle<true>(make_float4(t.v0.x, t.v0.y, t.v0.z, 0.0f), make_float4(e1.x, e1.y, e1.z, 0.0f),
+                       make_float4(e2.x, e2.y, e2.z, 0.0f), 0, origin, dir, nearest, hi, ht, hu, hv);
+    return hi >= 0 ? ht : -1.0f;
+}
 
 __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
                                                           rt_rect tile, int bounce, RtCountersDev *counters) {
@@ -210,8 +222,10 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
                 const int li = __float_as_int(bo.w);
                 const LightTri light = loadLight(sc, li);
                 const int conds = __float_as_int(pd.z);
-                const bool vis1 = sameTriangle(sc, wf.rayHit[i].x, light);
-                const bool vis2 = sameTriangle(sc, wf.rayHit[cap + i].x, light);
+                const int h1 = wf.rayHit[i].x, h2 = wf.rayHit[cap + i].x;
+                const bool fast = (p.flags & RT_FLAG_FAST_SHADOWS) != 0; // then -2 = "nothing nearer than the light"
+                const bool vis1 = fast ? h1 == WF_HIT_UNBLOCKED : sameTriangle(sc, h1, light);
+                const bool vis2 = fast ? h2 == WF_HIT_UNBLOCKED : sameTriangle(sc, h2, light);
                 const f3 Ke30 = ld3(fetchMtl(sc, light.mtlIndex).Ke) * 30.0f;
                 const float light_prob = 1.0f / (float)p.numEmitters;
                 const f3 Ld = estimateDirectResolve(F3(a1.x, a1.y, a1.z), a1.w, pd.x, conds & 1, F3(a2.x, a2.y, a2.z),
@@ -284,6 +298,13 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
                     rO[2] = make_float4(o2.x, o2.y, o2.z, alive ? 1.0f : 0.0f);
                     rD[0] = make_float4(T.wi1.x, T.wi1.y, T.wi1.z, 0.0f);
                     rD[1] = make_float4(T.wi2.x, T.wi2.y, T.wi2.z, 0.0f);
+                    if (p.flags & RT_FLAG_FAST_SHADOWS) { // rd.w = distance of the light; rays that miss it are not cast
+                        const float t1 = lightDistance(light, o2, T.wi1), t2 = lightDistance(light, o2, T.wi2);
+                        rD[0].w = t1;
+                        rD[1].w = t2;
+                        if (!(t1 >= 0.0f)) rO[0].w = 0.0f;
+                        if (!(t2 >= 0.0f)) rO[1].w = 0.0f;
+                    }
                     rD[2] = make_float4(wi.x, wi.y, wi.z, 0.0f);
                     requeue = true;
                 }
@@ -306,6 +327,8 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
             for (int k = 0; k < 3; ++k) {
                 wf.rayO[(bounce + 1) & 1][k * cap + slot] = rO[k];
                 wf.rayD[(bounce + 1) & 1][k * cap + slot] = rD[k];
+                if (k < 2 && (p.flags & RT_FLAG_FAST_SHADOWS) && rO[k].w == 0.0f)
+                    wf.rayHit[k * cap + slot] = make_int4(-1, 0, 0, 0); // never cast: "something else is nearest"
             }
         }
     }
@@ -360,7 +383,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     bool active = false;
     size_t slot = 0;
     f3 origin = F3(0, 0, 0), dir = F3(0, 0, 0), invdir = F3(0, 0, 0);
-    bool ltx = false, lty = false, ltz = false;
+    bool ltx = false, lty = false, ltz = false, bounded = false;
     int next = -1, iterations = 0, hitTri = -1;
     unsigned tests = 0;
     float nearest = 0.0f, hitT = 0.0f, hitU = 0.0f, hitV = 0.0f;
@@ -404,7 +427,9 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                         lty = invdir.y < 0.0f;
                         ltz = invdir.z < 0.0f;
                         next = 0;
-                        nearest = __builtin_inff();
+                        // rd.w > 0 (RT_FLAG_FAST_SHADOWS, shadow kinds only): look no further than the light
+                        bounded = rd.w > 0.0f;
+                        nearest = bounded ? rd.w : __builtin_inff();
                         iterations = 0;
                         tests = 0;
                         hitTri = -1;
@@ -428,6 +453,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             if (iterations > p.maxFollows) { // trace3.cs:228-234
                 hitTri = -1;
                 next = -1;
+                bounded = false; // an aborted walk proves nothing: reported as a miss, i.e. not visible
                 break;
             }
             float4 b0, b1;
@@ -529,8 +555,10 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 testLeaf<false>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
                 tests += (unsigned)leafCount;
             }
+            if (bounded && hitTri >= 0) next = -1; // any hit nearer than the light settles a shadow ray
         } else if (active && next == -1) {
             // the walk is over: publish the closest hit and free the lane
+            if (bounded && hitTri < 0) hitTri = WF_HIT_UNBLOCKED;
             wf.rayHit[slot] = make_int4(hitTri, __float_as_int(hitT), __float_as_int(hitU), __float_as_int(hitV));
             if (wantWork) wf.rayWork[slot] = make_int2(iterations, (int)tests);
             cRays++;

@@ -290,3 +290,20 @@ def test_error_paths(ctx):
     ctx.upload(4, wl.buffers[4][: 128 * 100])
     assert L.rt_trace(ctx._h, ctypes.byref(p), None) == -6
     ctx.upload_scene(wl.buffers)
+
+
+@pytest.mark.parametrize("scene,w,h,spp,mb", [("room", 240, 135, 3, 5), ("scene", 400, 225, 4, 5)])
+def test_fast_shadows_flag_gives_the_same_picture(ctx, scene, w, h, spp, mb):
+    """RT_FLAG_FAST_SHADOWS (opt-in, not the reference's algorithm): shadow rays that miss their light are not
+    cast, the others stop at the first hit nearer than the light.  The visibility answers, hence the image, are
+    those of the reference's closest-hit formulation (up to exact-distance ties); far fewer rays are traced."""
+    wl = workloads.Workload(scene, w, h)
+    ref = render(ctx, wl, spp, mb)
+    c0 = ctx.counters()
+    fast = render(ctx, wl, spp, mb, flags=hiplib.FLAG_AUX | hiplib.FLAG_FAST_SHADOWS)
+    c1 = ctx.counters()
+    assert_ids_equal(fast, ref)
+    same = (fast["color"].view(np.uint32) == ref["color"].view(np.uint32)).all(-1).mean()
+    assert same > 0.999, same
+    assert_radiance_close(ref["color"], fast["color"], f"fast shadows {scene}")
+    assert (c1.rays - c1.paths) < 0.8 * (c0.rays - c0.paths) and c1.node_visits < c0.node_visits  # secondary rays
