@@ -98,6 +98,10 @@ class TiledFrame:
         pad[: mine.shape[0]] = mine
         recv = [torch.empty_like(pad) for _ in range(self.world)] if self.rank == 0 else None
         dist.gather(pad, recv, dst=0)
+        if pad.is_cuda:
+            # the launcher copies on its own HIP stream: the collective (and the staging copy above) must have
+            # finished before rank 0 pastes the strips, and before the next frame re-uses the staging memory
+            torch.cuda.current_stream(pad.device).synchronize()
         if self.rank == 0:
             for r in range(1, self.world):
                 y0, y1 = strip_rows(self.height, self.world, r)
