@@ -42,6 +42,19 @@ __device__ __forceinline__ int waveAppend(int *counter, bool want) {
     return want ? base + __popcll(mask & ((1ull << lane) - 1ull)) : -1;
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP moves (a handful of VALU operations) instead of six LDS-crossbar
+// shuffles: Hillis-Steele inside each row of 16 lanes (row_shr 1, 2, 4, 8, zero fill), then the row totals are
+// carried over with row_bcast15 (rows 1 and 3 take the last lane of the row before) and row_bcast31 (rows 2 and 3).
+__device__ __forceinline__ int waveInclusiveScan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
 __device__ __forceinline__ PathCtx makeCtx(const WfParams &p, int x, int y, int sample, int seed) {
     PathCtx c;
     c.px = x;
@@ -483,13 +496,8 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         // smallest t below the ray's current nearest (strict `<`, trace3.cs:177).
         if (coop) {
             const int cnt = (active && leafCount > 0) ? leafCount : 0;
-            int incl = cnt;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int v = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += v;
-            }
-            const int totalTests = __shfl(incl, 63, 64);
+            const int incl = waveInclusiveScan(cnt);
+            const int totalTests = __builtin_amdgcn_readlane(incl, 63);
             if (totalTests > 0) {
                 const int excl = incl - cnt;
                 ws->first[lane] = leafFirst - excl; // triangle of pair g is first[owner] + g
