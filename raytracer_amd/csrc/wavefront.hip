@@ -86,17 +86,23 @@ __device__ __forceinline__ void flushCounters(const WfParams &p, RtCountersDev *
 // ------------------------------------------------------------------------------------------ primary
 __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
                                                             rt_rect tile, int tilesX, int tilesY, int xcdRemap,
-                                                            RtCountersDev *counters) {
+                                                            int logicalBlocks, RtCountersDev *counters) {
     const int tilesPerSample = tilesX * tilesY;
-    const int nblocks = gridDim.x;
-    const int b = blockIdx.x;
-    const int perXcd = nblocks / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx = (lane & 7) + 8 * (wave & 1), ly = (lane >> 3) + 8 * (wave >> 1);
+    const int W = img.width, H = img.height;
+    const int perXcd = logicalBlocks / 8;
+    const int cacheWanted = sc.cacheNodes;
+    bool cacheFilled = false;
+    sc.cacheNodes = 0;
+    unsigned nPaths = 0, nVisits = 0, nTests = 0;
+    // A block walks over several 16x16 tiles: most tiles of the named scenes only see the sky and take a few
+    // hundred cycles, less than it costs to start a block for each.
+    for (int b = blockIdx.x; b < logicalBlocks; b += gridDim.x) {
     const int t = xcdRemap ? (b % 8) * perXcd + b / 8 : b;
     const bool live = t < tilesPerSample * p.batch;
     const int sample = live ? t / tilesPerSample : 0;
     const int ts = t - sample * tilesPerSample;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int lx = (lane & 7) + 8 * (wave & 1), ly = (lane >> 3) + 8 * (wave >> 1);
     const int x = tile.x0 + (ts % tilesX) * 16 + lx, y = tile.y0 + (ts / tilesX) * 16 + ly;
     const bool active = live && x < tile.x1 && y < tile.y1;
 
@@ -106,7 +112,6 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
     h.tridx = -1;
     h.t = h.u = h.v = 0.0f;
     f3 dir = F3(0, 0, 0);
-    const int W = img.width, H = img.height;
     f3 invdir = F3(0, 0, 0);
     bool entersScene = false;
     if (active) {
@@ -124,11 +129,14 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
         const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
         entersScene = maxt >= 0.0f && mint <= maxt * 1.00000024f;
     }
-    // Only the tiles that see the scene's bounding box copy the top of the tree into LDS (a few per cent of the
-    // tiles for the named scenes under the survey's camera); the others finish after their one root test.
-    if (sc.cacheNodes > 0) {
-        if (__syncthreads_or(entersScene)) fillNodeCache(sc);
-        else sc.cacheNodes = 0;
+    // Only blocks that see the scene's bounding box copy the top of the tree into LDS (a few per cent of the
+    // tiles for the named scenes under the survey's camera); the other tiles finish after their one root test.
+    if (cacheWanted > 0 && !cacheFilled) {
+        if (__syncthreads_or(entersScene)) {
+            sc.cacheNodes = cacheWanted;
+            fillNodeCache(sc);
+            cacheFilled = true;
+        }
     }
     if (active) {
         traverse(sc, c, ld3(p.eye), dir, invdir, h);
@@ -140,8 +148,12 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
         if (h.tridx == -1) {
             // trace(): L += beta * SKY_COLOR; write(vec3(0), vec3(0)); break   (trace3.cs:639-647)
             const f3 L = F3(0, 0, 0) + F3(1, 1, 1) * F3(0.89f, 0.96f, 1.00f);
-            img.normal[pix] = 0u;
-            img.pos[pix] = make_uint2(pack_half2_rtz(0.0f, 0.0f), pack_half2_rtz(0.0f, 1.0f));
+            // every sample of the batch would store the same G-buffer texel (the primary ray does not depend on
+            // the sample); the last one does it, as successive dispatches would leave it
+            if (sample == p.batch - 1) {
+                img.normal[pix] = 0u;
+                img.pos[pix] = make_uint2(pack_half2_rtz(0.0f, 0.0f), pack_half2_rtz(0.0f, 1.0f));
+            }
             const int tp = (y - tile.y0) * (tile.x1 - tile.x0) + (x - tile.x0);
             wf.radiance[(size_t)sample * wf.tilePixels + tp] = make_float4(L.x, L.y, L.z, 1.0f);
             // the statistics image shows the last sample of the batch, as successive dispatches would leave it
@@ -164,19 +176,22 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
         wf.rayHit[r] = make_int4(h.tridx, __float_as_int(h.t), __float_as_int(h.u), __float_as_int(h.v));
         if (p.flags & RT_FLAG_PIXEL_STATS) wf.pathStats[slot] = make_int4((int)c.rays, (int)c.visits, (int)c.tests, 0);
     }
-    if (!(p.flags & RT_FLAG_NO_COUNTERS)) { // one primary ray per active lane: three sums feed six counters
+    nPaths += active ? 1u : 0u;
+    nVisits += c.visits;
+    nTests += c.tests;
+    }
+    if (!(p.flags & RT_FLAG_NO_COUNTERS)) { // one primary ray per path: three sums feed six counters
         RtCountersDev *cs = counterShard(counters);
-        const unsigned long long act = __ballot(active);
-        unsigned v = c.visits, t = c.tests;
+        unsigned n = nPaths, v = nVisits, t = nTests;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
+            n += __shfl_down(n, off, 64);
             v += __shfl_down(v, off, 64);
             t += __shfl_down(t, off, 64);
         }
-        if (lane == 0 && act) {
-            const unsigned long long n = (unsigned long long)__popcll(act);
-            atomicAdd(&cs->rays, n);
-            atomicAdd(&cs->paths, n);
+        if (lane == 0 && n) {
+            atomicAdd(&cs->rays, (unsigned long long)n);
+            atomicAdd(&cs->paths, (unsigned long long)n);
             if (v) { atomicAdd(&cs->node_visits, (unsigned long long)v); atomicAdd(&cs->primary_visits, (unsigned long long)v); }
             if (t) { atomicAdd(&cs->tri_tests, (unsigned long long)t); atomicAdd(&cs->primary_tests, (unsigned long long)t); }
         }
@@ -286,7 +301,7 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
                 } else {
                     L = L + beta * F3(0.89f, 0.96f, 1.00f);
                 }
-                if (bounce == 0) { // write(), trace3.cs:357-361 (a miss at bounce 0 never reaches this kernel)
+                if (bounce == 0 && sample == p.batch - 1) { // write(), trace3.cs:357-361 (misses are stored by the primary kernel)
                     img.normal[pix] = snorm8(SI.normal.x) | (snorm8(SI.normal.y) << 8) | (snorm8(SI.normal.z) << 16);
                     img.pos[pix] = make_uint2(pack_half2_rtz(SI.point.x, SI.point.y), pack_half2_rtz(SI.point.z, 1.0f));
                 }
@@ -626,8 +641,9 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     scPrimary.cacheNodes = sc.packedLeaves ? std::max(0, std::min(sc.numNodes, std::min(p.extendCacheNodes, 1024))) : 0;
     scExtend.cacheNodes = sc.packedLeaves ? std::max(0, std::min(sc.numNodes, p.extendCacheNodes)) : 0;
     const size_t extendLds = (size_t)scExtend.cacheNodes * 32 + 4 * sizeof(WaveShare);
-    hipLaunchKernelGGL(rt_wf_primary_kernel, dim3(nblocks), dim3(256), (size_t)scPrimary.cacheNodes * 32, stream, scPrimary,
-                       img, p, wf, tile, tilesX, tilesY, xcdRemap, counters);
+    const int primaryBlocks = std::min(nblocks, 256 * p.primaryBlocksPerCU);
+    hipLaunchKernelGGL(rt_wf_primary_kernel, dim3(primaryBlocks), dim3(256), (size_t)scPrimary.cacheNodes * 32, stream,
+                       scPrimary, img, p, wf, tile, tilesX, tilesY, xcdRemap, nblocks, counters);
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, false);
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
     const int logicBlocks = 256 * 4, extendBlocks = 256 * p.extendBlocksPerCU;
