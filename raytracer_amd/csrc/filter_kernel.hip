@@ -33,6 +33,16 @@ __device__ __forceinline__ float4 unpackSnorm4(uint32_t n) {
                        snorm8_to_float(n >> 24));
 }
 
+// x / d for a divisor that is the same for every tap of a pass: q = x * (1/d) corrected by one fused residual
+// step, q' = q + (x - q*d) * (1/d).  For finite, normal operands this is the correctly rounded quotient that the
+// full IEEE division sequence returns (three instructions instead of about twelve); an infinite divisor (c_phi of
+// pass 0, reference src/filter.cpp:81: 1.0f / 0 * 3.3) gives x * 0 = 0 like x / inf.
+__device__ __forceinline__ float divUniform(float x, float d, float rd) {
+    const float q = x * rd;
+    if (!(fabsf(d) < __builtin_inff())) return q;
+    return __fmaf_rn(__fmaf_rn(-q, d, x), rd, q);
+}
+
 } // namespace
 
 // colorF32 != nullptr: pass 0 (reads the RGBA32F accumulation image); else reads colorF16.
@@ -81,6 +91,7 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
     const float4 pval = unpackHalf4(sPos[centre]);
     const float kern[3] = {1.0f / 16, 1.0f / 8, 1.0f / 4}; // filter.cpp:41-43 by |ox|+|oy|: 2→1/16, 1→1/8, 0→1/4
     const float stepsq = (float)(step * step);
+    const float r_c = 1.0f / c_phi, r_n = 1.0f / n_phi, r_p = 1.0f / p_phi, r_s = 1.0f / stepsq;
 
     float4 sum = make_float4(0, 0, 0, 0);
     float cum_w = 0.0f;
@@ -92,12 +103,12 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
             const float4 ctmp = sCol[e];
             if (ctmp.x != ctmp.x || ctmp.y != ctmp.y || ctmp.z != ctmp.z || ctmp.w != ctmp.w) continue;
             float4 t = sub4(cval, ctmp);
-            const float c_w = fminf(expf(-dot4(t, t) / c_phi), 1.0f);
+            const float c_w = fminf(expf(divUniform(-dot4(t, t), c_phi, r_c)), 1.0f);
             t = sub4(nval, unpackSnorm4(sNrm[e]));
-            const float dist2 = fmaxf(dot4(t, t) / stepsq, 0.0f);
-            const float n_w = fminf(expf(-dist2 / n_phi), 1.0f);
+            const float dist2 = fmaxf(divUniform(dot4(t, t), stepsq, r_s), 0.0f);
+            const float n_w = fminf(expf(divUniform(-dist2, n_phi, r_n)), 1.0f);
             t = sub4(pval, unpackHalf4(sPos[e]));
-            const float p_w = fminf(expf(-dot4(t, t) / p_phi), 1.0f);
+            const float p_w = fminf(expf(divUniform(-dot4(t, t), p_phi, r_p)), 1.0f);
             const float weight = c_w * n_w * p_w;
             const float k = kern[2 - (ox != 0) - (oy != 0)];
             sum.x += ctmp.x * weight * k;
