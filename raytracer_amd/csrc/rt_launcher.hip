@@ -67,7 +67,7 @@ struct rt_ctx {
     size_t wfCapacity = 0, wfRadianceSlots = 0;
     int tuneRefillLanes = 64, tuneExtendBlocks = 4; // development knobs: RT_WF_REFILL, RT_WF_BLOCKS
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
-    int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 1, tuneChunk = 64, tunePrimaryBlocks = 32;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
+    int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 1, tuneChunk = 64, tunePrimaryBlocks = 32, tunePrimaryVia = -1;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
     int tuneCacheNodes = 640;                        // RT_WF_CACHE_NODES: 20 KB + 19 KB of wave scratch per block, 4 blocks per CU
 
     DevBuf counters;
@@ -262,6 +262,7 @@ int rt_create(int device_id, rt_ctx **out) {
     if (const char *e = std::getenv("RT_WF_RAYS_PER_WAVE")) c->tuneRaysPerWave = std::max(0, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_FILL")) c->tuneFill = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_PRIMARY_BLOCKS")) c->tunePrimaryBlocks = std::max(1, std::min(1 << 20, std::atoi(e)));
+    if (const char *e = std::getenv("RT_WF_PRIMARY_VIA_EXTEND")) c->tunePrimaryVia = std::atoi(e);
     if (const char *e = std::getenv("RT_WF_CHUNK")) c->tuneChunk = std::max(8, std::min(65536, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_COOP")) c->tuneCoop = std::atoi(e);
     if (const char *e = std::getenv("RT_WF_BLOCKS")) c->tuneExtendBlocks = std::max(1, std::min(8, std::atoi(e)));
@@ -593,6 +594,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         wp.refillLanes = c->tuneRefillLanes;
         wp.extendBlocksPerCU = c->tuneExtendBlocks;
         wp.primaryBlocksPerCU = c->tunePrimaryBlocks;
+        wp.primaryViaExtend = c->tunePrimaryVia >= 0 ? c->tunePrimaryVia : (hot > (size_t)3 * 1024 * 1024 ? 1 : 0);
         wp.extendCacheNodes = c->tuneCacheNodes;
         wp.extendRaysPerWave = c->tuneRaysPerWave;
         wp.extendFill = c->tuneFill;

@@ -14,6 +14,7 @@ struct WfParams {
     float eye[3], ray00[3], ray01[3], ray10[3], ray11[3];
     int maxBounces, numEmitters, maxFollows, flags, batch;
     int refillLanes;       // idle lanes of a wave that trigger a refill from the ray queue (64 = only when all are idle)
+    int primaryViaExtend;   // primary rays that enter the scene box are walked by the extend kernel (stage 0)
     int primaryBlocksPerCU; // the primary kernel's blocks walk over the 16x16 tiles; this many blocks per CU
     int extendBlocksPerCU; // persistent 256-thread blocks per CU of the extend kernel
     int extendCacheNodes;  // nodes the extend kernel keeps in LDS (40 bytes each, per block)

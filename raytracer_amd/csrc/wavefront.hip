@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
     const int cacheWanted = sc.cacheNodes;
     bool cacheFilled = false;
     sc.cacheNodes = 0;
-    unsigned nPaths = 0, nVisits = 0, nTests = 0;
+    unsigned nPaths = 0, nRays = 0, nVisits = 0, nTests = 0;
     // A block walks over several 16x16 tiles: most tiles of the named scenes only see the sky and take a few
     // hundred cycles, less than it costs to start a block for each.
     for (int b = blockIdx.x; b < logicalBlocks; b += gridDim.x) {
@@ -138,14 +138,20 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
             cacheFilled = true;
         }
     }
+    // p.primaryViaExtend: rays that get past the root are not walked here but queued for the extend kernel
+    // (stage 0), which has the cooperative leaf tests and coalesced triangle reads that pay off for scenes beyond
+    // the caches; rays that miss the root box finish here as before (one node visit).
+    const bool defer = p.primaryViaExtend && entersScene;
     if (active) {
-        traverse(sc, c, ld3(p.eye), dir, invdir, h);
+        if (!defer) traverse(sc, c, ld3(p.eye), dir, invdir, h);
         const size_t pix = (size_t)y * W + x;
-        if (p.flags & RT_FLAG_AUX) {
+        if ((p.flags & RT_FLAG_AUX) && !defer) {
             img.tridx[pix] = h.tridx;
             img.visits[pix] = c.lastIterations;
         }
-        if (h.tridx == -1) {
+        if (defer) {
+            queued = true;
+        } else if (h.tridx == -1) {
             // trace(): L += beta * SKY_COLOR; write(vec3(0), vec3(0)); break   (trace3.cs:639-647)
             const f3 L = F3(0, 0, 0) + F3(1, 1, 1) * F3(0.89f, 0.96f, 1.00f);
             // every sample of the batch would store the same G-buffer texel (the primary ray does not depend on
@@ -177,20 +183,22 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
         if (p.flags & RT_FLAG_PIXEL_STATS) wf.pathStats[slot] = make_int4((int)c.rays, (int)c.visits, (int)c.tests, 0);
     }
     nPaths += active ? 1u : 0u;
+    nRays += (active && !defer) ? 1u : 0u;
     nVisits += c.visits;
     nTests += c.tests;
     }
     if (!(p.flags & RT_FLAG_NO_COUNTERS)) { // one primary ray per path: three sums feed six counters
         RtCountersDev *cs = counterShard(counters);
-        unsigned n = nPaths, v = nVisits, t = nTests;
+        unsigned n = nPaths, r = nRays, v = nVisits, t = nTests;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             n += __shfl_down(n, off, 64);
+            r += __shfl_down(r, off, 64);
             v += __shfl_down(v, off, 64);
             t += __shfl_down(t, off, 64);
         }
         if (lane == 0 && n) {
-            atomicAdd(&cs->rays, (unsigned long long)n);
+            if (r) atomicAdd(&cs->rays, (unsigned long long)r);
             atomicAdd(&cs->paths, (unsigned long long)n);
             if (v) { atomicAdd(&cs->node_visits, (unsigned long long)v); atomicAdd(&cs->primary_visits, (unsigned long long)v); }
             if (t) { atomicAdd(&cs->tri_tests, (unsigned long long)t); atomicAdd(&cs->primary_tests, (unsigned long long)t); }
@@ -274,11 +282,15 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
                 const int4 hr = wf.rayHit[r];
                 const float4 ro = wf.rayO[bounce & 1][r], rd = wf.rayD[bounce & 1][r];
                 const f3 origin = F3(ro.x, ro.y, ro.z), dir = F3(rd.x, rd.y, rd.z);
-                if (wantStats && bounce > 0) {
+                if (wantStats && (bounce > 0 || p.primaryViaExtend)) {
                     const int2 w2 = wf.rayWork[r];
                     stats.x += 1;
                     stats.y += w2.x;
                     stats.z += w2.y;
+                }
+                if (bounce == 0 && p.primaryViaExtend && (p.flags & RT_FLAG_AUX)) { // the primary walk ran in the extend kernel
+                    img.tridx[pix] = hr.x;
+                    img.visits[pix] = wf.rayWork[r].x;
                 }
                 // intersectGeometry's epilogue (trace3.cs:259-276)
                 Surface SI;
@@ -384,12 +396,14 @@ struct WaveShare { // phase-2 exchange area of one wave (4.75 KB)
 __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams p, WfBuffers wf, int stage,
                                                            int refillLanes, RtCountersDev *counters) {
     const int n = min(wf.counts[stage], wf.capacity);
-    const int total = 3 * n;
+    // stage 0 (deferred primary rays) holds one ray per path, in the continuation segment; later stages three
+    const int kinds = stage == 0 ? 1 : 3, kindBase = stage == 0 ? 2 : 0;
+    const int total = kinds * n;
     const size_t cap = (size_t)wf.capacity;
     const int lane = threadIdx.x & 63;
     const unsigned long long lanesBelow = (1ull << lane) - 1ull;
     const float4 *rayO = wf.rayO[stage & 1], *rayD = wf.rayD[stage & 1];
-    const bool wantWork = (p.flags & RT_FLAG_PIXEL_STATS) != 0;
+    const bool wantWork = (p.flags & RT_FLAG_PIXEL_STATS) != 0 || (stage == 0 && (p.flags & RT_FLAG_AUX) != 0);
     int *cursor = &wf.counts[32 + stage];
     // Rays per wave.  With fewer rays than ray slots on the chip (a sparse bounce: scene.obj has ~140 k secondary
     // rays per launch for 262 144 slots) a wave takes only `raysPerWave` rays into its first lanes, so that the work
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 const int w = base + __popcll(idle & lanesBelow);
                 if (w < chunkEnd) {
                     const int kind = w / n, j = w - kind * n;
-                    slot = kind * cap + j;
+                    slot = (size_t)(kind + kindBase) * cap + j;
                     const float4 ro = rayO[slot];
                     if (ro.w != 0.0f) {
                         const float4 rd = rayD[slot];
@@ -595,6 +609,10 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     c.visits = cVisits;
     c.tests = cTests;
     flushCounters(p, counters, c, 0u);
+    if (stage == 0 && !(p.flags & RT_FLAG_NO_COUNTERS)) {
+        waveAdd(&counterShard(counters)->primary_visits, cVisits);
+        waveAdd(&counterShard(counters)->primary_tests, cTests);
+    }
 }
 
 // ------------------------------------------------------------------------------------------ blend
@@ -638,7 +656,7 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, true);
     RtScene scPlain = sc, scExtend = sc, scPrimary = sc;
     scPlain.cacheNodes = 0;
-    scPrimary.cacheNodes = sc.packedLeaves ? std::max(0, std::min(sc.numNodes, std::min(p.extendCacheNodes, 1024))) : 0;
+    scPrimary.cacheNodes = (sc.packedLeaves && !p.primaryViaExtend) ? std::max(0, std::min(sc.numNodes, std::min(p.extendCacheNodes, 1024))) : 0;
     scExtend.cacheNodes = sc.packedLeaves ? std::max(0, std::min(sc.numNodes, p.extendCacheNodes)) : 0;
     const size_t extendLds = (size_t)scExtend.cacheNodes * 32 + 4 * sizeof(WaveShare);
     const int primaryBlocks = std::min(nblocks, 256 * p.primaryBlocksPerCU);
@@ -647,6 +665,12 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, false);
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
     const int logicBlocks = 256 * 4, extendBlocks = 256 * p.extendBlocksPerCU;
+    if (p.primaryViaExtend) {
+        if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, true);
+        hipLaunchKernelGGL(rt_wf_extend_kernel, dim3(extendBlocks), dim3(256), extendLds, stream, scExtend, p, wf, 0,
+                           p.refillLanes, counters);
+        if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, false);
+    }
     for (int b = 0; b <= p.maxBounces; ++b) {
         if (prof) rtMarkKernel(prof, RT_TIME_WF_LOGIC, true);
         hipLaunchKernelGGL(rt_wf_logic_kernel, dim3(logicBlocks), dim3(256), 0, stream, scPlain, img, p, wf, tile, b, counters);
