@@ -170,3 +170,29 @@ def test_png_writer(tmp_path):
     raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(37, 1 + 53 * 4)
     assert np.all(raw[:, 0] == 0)
     assert np.array_equal(raw[:, 1:].reshape(37, 53, 4), img[::-1])  # flipped like stbi_flip_vertically_on_write
+
+
+def test_pcg32_known_answers():
+    """PCG XSH-RR 64/32 of the lattice generator: the published outputs of pcg32_srandom(42, 54)."""
+    L = hostlib.lib()
+    want = [0xa15c02b7, 0x7b47f409, 0xba1d3330, 0x83d2f293, 0xbfa4784b, 0xcbed606e]
+    assert [L.rth_pcg32_nth(42, 54, i) for i in range(6)] == want
+
+
+def test_lattice_workload_is_deterministic_and_flat():
+    """SURVEY 8(d) config #5 generator at a small size: copies * 968 triangles + the 2-triangle light, one object,
+    reproducible from the seed, every leaf within the builder's limit."""
+    from raytracer_amd import workloads
+    a = workloads.LatticeWorkload(64, 36, 3, 2, 2)
+    b = workloads.LatticeWorkload(64, 36, 3, 2, 2)
+    c = workloads.LatticeWorkload(64, 36, 3, 2, 2, seed=7)
+    assert a.info.num_triangles == 3 * 2 * 2 * 968 + 2 and a.info.num_emitters == 2
+    assert bytes(a.buffers[4]) == bytes(b.buffers[4]) and bytes(a.buffers[3]) == bytes(b.buffers[3])
+    assert bytes(a.buffers[4]) != bytes(c.buffers[4])
+    nodes = np.frombuffer(bytes(a.buffers[3]), hostlib.NODE_DTYPE)
+    assert nodes["numTris"].max() <= 32 and nodes["numTris"].sum() == a.info.num_triangles
+    tris = np.frombuffer(bytes(a.buffers[4]), hostlib.TRI_DTYPE)
+    n = np.linalg.norm(tris["n0"][: -2], axis=1)       # rotations keep the normals' length
+    assert np.allclose(n, 1.0, atol=1e-3)
+    ext = np.array(a.info.bbox_max[:]) - np.array(a.info.bbox_min[:])
+    assert ext[0] > ext[1] * 0.9 and ext[0] > 2.0      # 3 cells along x, 2 along y / z
