@@ -222,7 +222,7 @@ __device__ __forceinline__ float lightDistance(const LightTri &t, f3 origin, f3 
     return hi >= 0 ? ht : -1.0f;
 }
 
-__global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void rt_wf_logic_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
                                                           rt_rect tile, int bounce, RtCountersDev *counters) {
     const int n = min(wf.counts[bounce], wf.capacity);
     const int *qin = wf.queue[bounce & 1];
@@ -231,25 +231,30 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
     const int W = img.width;
     const int rounds = (n + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
     unsigned shaded = 0;
+    const bool wantStats = (p.flags & RT_FLAG_PIXEL_STATS) != 0;
     for (int round = 0; round < rounds; ++round) {
         const int i = (round * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
         const bool have = i < n;
+        // Part 1: finish the previous bounce, shade this bounce's hit, decide whether the path goes on.  What is kept
+        // across the queue append below is only what part 2 needs (the kernel is register-bound: every value held
+        // here costs occupancy).
         bool requeue = false;
-        int pid = 0;
-        // values the re-queue step needs
-        float4 rO[3], rD[3];
+        int pid = 0, pix = 0, sample = 0, seed = 0;
+        f3 L = F3(0, 0, 0), beta = F3(0, 0, 0), dir = F3(0, 0, 0);
+        Surface SI;
+        SI.tridx = -1; SI.matidx = 0; SI.normal = SI.point = F3(0, 0, 0);
+        int4 stats = make_int4(0, 0, 0, 0);
         if (have) {
             pid = qin[i];
             const uint2 ps = wf.pixSample[pid];
-            const int pix = (int)ps.x, sample = (int)ps.y;
-            const int x = pix % W, y = pix / W;
-            float4 Ls = wf.L_seed[pid];
-            float4 bt = wf.beta[pid];
-            f3 L = F3(Ls.x, Ls.y, Ls.z), beta = F3(bt.x, bt.y, bt.z);
-            int flags = __float_as_int(bt.w);
-            PathCtx c = makeCtx(p, x, y, sample, __float_as_int(Ls.w));
-            int4 stats = make_int4(0, 0, 0, 0);
-            const bool wantStats = (p.flags & RT_FLAG_PIXEL_STATS) != 0;
+            pix = (int)ps.x;
+            sample = (int)ps.y;
+            const float4 Ls = wf.L_seed[pid];
+            const float4 bt = wf.beta[pid];
+            L = F3(Ls.x, Ls.y, Ls.z);
+            beta = F3(bt.x, bt.y, bt.z);
+            seed = __float_as_int(Ls.w);
+            const int flags = __float_as_int(bt.w);
             if (wantStats) stats = wf.pathStats[pid];
 
             if (flags & WF_FLAG_PENDING) {
@@ -275,13 +280,13 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
                 }
             }
 
-            bool finished = (flags & WF_FLAG_ENDED) != 0;
-            if (!finished) {
+            if (!(flags & WF_FLAG_ENDED)) {
                 // the hit of this bounce: result of the continuation (or primary) ray
                 const size_t r = 2 * cap + i;
                 const int4 hr = wf.rayHit[r];
                 const float4 ro = wf.rayO[bounce & 1][r], rd = wf.rayD[bounce & 1][r];
-                const f3 origin = F3(ro.x, ro.y, ro.z), dir = F3(rd.x, rd.y, rd.z);
+                const f3 origin = F3(ro.x, ro.y, ro.z);
+                dir = F3(rd.x, rd.y, rd.z);
                 if (wantStats && (bounce > 0 || p.primaryViaExtend)) {
                     const int2 w2 = wf.rayWork[r];
                     stats.x += 1;
@@ -293,11 +298,7 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
                     img.visits[pix] = wf.rayWork[r].x;
                 }
                 // intersectGeometry's epilogue (trace3.cs:259-276)
-                Surface SI;
                 SI.tridx = hr.x;
-                SI.normal = F3(0, 0, 0);
-                SI.point = F3(0, 0, 0);
-                SI.matidx = 0;
                 const RtTri128 *tri = triPtr(sc, hr.x);
                 if (tri) {
                     const float u = __int_as_float(hr.z), v = __int_as_float(hr.w), w = 1.0f - u - v;
@@ -307,8 +308,8 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
                     shaded++;
                 }
                 const bool found = SI.tridx != -1;
-                const RtMtl m = fetchMtl(sc, SI.matidx);
                 if (found) {
+                    const RtMtl m = fetchMtl(sc, SI.matidx);
                     if (m.emitter) L = L + (beta * ld3(m.Ke)) * 30.0f;
                 } else {
                     L = L + beta * F3(0.89f, 0.96f, 1.00f);
@@ -317,59 +318,56 @@ __global__ __launch_bounds__(256) void rt_wf_logic_kernel(RtScene sc, RtImages i
                     img.normal[pix] = snorm8(SI.normal.x) | (snorm8(SI.normal.y) << 8) | (snorm8(SI.normal.z) << 16);
                     img.pos[pix] = make_uint2(pack_half2_rtz(SI.point.x, SI.point.y), pack_half2_rtz(SI.point.z, 1.0f));
                 }
-                if (!found || bounce >= p.maxBounces) {
-                    finished = true;
-                } else {
-                    const f3 o2 = SI.point + SI.normal * EPSILON_F;
-                    float light_prob;
-                    const int li = pickLight(c, bounce, p.numEmitters, light_prob);
-                    const LightTri light = loadLight(sc, li);
-                    DirectTerms T;
-                    estimateDirectPrepare(c, o2, dir, SI.normal, m, bounce, light, T);
-                    const f3 betaOld = beta;
-                    f3 wi;
-                    const bool alive = continuePath(c, bounce, SI.normal, m, dir, beta, wi);
-                    wf.betaOld[pid] = make_float4(betaOld.x, betaOld.y, betaOld.z, __int_as_float(li));
-                    wf.f1w1[pid] = make_float4(T.f1.x, T.f1.y, T.f1.z, T.w1);
-                    wf.f2w2[pid] = make_float4(T.f2.x, T.f2.y, T.f2.z, T.w2);
-                    wf.pdfs[pid] = make_float4(T.lp1, T.bp2, __int_as_float(T.cond1 | (T.cond2 << 1)), 0.0f);
-                    flags = WF_FLAG_PENDING | (alive ? 0 : WF_FLAG_ENDED);
-                    rO[0] = rO[1] = make_float4(o2.x, o2.y, o2.z, 1.0f);
-                    rO[2] = make_float4(o2.x, o2.y, o2.z, alive ? 1.0f : 0.0f);
-                    rD[0] = make_float4(T.wi1.x, T.wi1.y, T.wi1.z, 0.0f);
-                    rD[1] = make_float4(T.wi2.x, T.wi2.y, T.wi2.z, 0.0f);
-                    if (p.flags & RT_FLAG_FAST_SHADOWS) { // rd.w = distance of the light; rays that miss it are not cast
-                        const float t1 = lightDistance(light, o2, T.wi1), t2 = lightDistance(light, o2, T.wi2);
-                        rD[0].w = t1;
-                        rD[1].w = t2;
-                        if (!(t1 >= 0.0f)) rO[0].w = 0.0f;
-                        if (!(t2 >= 0.0f)) rO[1].w = 0.0f;
-                    }
-                    rD[2] = make_float4(wi.x, wi.y, wi.z, 0.0f);
-                    requeue = true;
-                }
+                requeue = found && bounce < p.maxBounces;
             }
-            if (requeue) {
-                wf.L_seed[pid] = make_float4(L.x, L.y, L.z, __int_as_float(c.seed));
-                wf.beta[pid] = make_float4(beta.x, beta.y, beta.z, __int_as_float(flags));
-                if (wantStats) wf.pathStats[pid] = stats;
-            } else {
+            if (!requeue) {
                 // the path is complete: hand its radiance to the blend step
+                const int x = pix % W, y = pix / W;
                 const int tp = (y - tile.y0) * (tile.x1 - tile.x0) + (x - tile.x0);
                 wf.radiance[(size_t)sample * wf.tilePixels + tp] = make_float4(L.x, L.y, L.z, 1.0f);
                 if (wantStats && sample == p.batch - 1) img.stats[pix] = stats;
             }
         }
         const int slot = waveAppend(&wf.counts[bounce + 1], requeue);
+        // Part 2: sample the light and the BRDF, emit the three rays of the next stage straight into their slots.
         if (requeue) {
-            qout[slot] = pid;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                wf.rayO[(bounce + 1) & 1][k * cap + slot] = rO[k];
-                wf.rayD[(bounce + 1) & 1][k * cap + slot] = rD[k];
-                if (k < 2 && (p.flags & RT_FLAG_FAST_SHADOWS) && rO[k].w == 0.0f)
-                    wf.rayHit[k * cap + slot] = make_int4(-1, 0, 0, 0); // never cast: "something else is nearest"
+            const int x = pix % W, y = pix / W;
+            PathCtx c = makeCtx(p, x, y, sample, seed);
+            const RtMtl m = fetchMtl(sc, SI.matidx);
+            float4 *outO = wf.rayO[(bounce + 1) & 1], *outD = wf.rayD[(bounce + 1) & 1];
+            const f3 o2 = SI.point + SI.normal * EPSILON_F;
+            float light_prob;
+            const int li = pickLight(c, bounce, p.numEmitters, light_prob);
+            const LightTri light = loadLight(sc, li);
+            {
+                DirectTerms T;
+                estimateDirectPrepare(c, o2, dir, SI.normal, m, bounce, light, T);
+                wf.f1w1[pid] = make_float4(T.f1.x, T.f1.y, T.f1.z, T.w1);
+                wf.f2w2[pid] = make_float4(T.f2.x, T.f2.y, T.f2.z, T.w2);
+                wf.pdfs[pid] = make_float4(T.lp1, T.bp2, __int_as_float(T.cond1 | (T.cond2 << 1)), 0.0f);
+                float t1 = 0.0f, t2 = 0.0f, c1 = 1.0f, c2 = 1.0f;
+                if (p.flags & RT_FLAG_FAST_SHADOWS) { // rd.w = distance of the light; rays that miss it are not cast
+                    t1 = lightDistance(light, o2, T.wi1);
+                    t2 = lightDistance(light, o2, T.wi2);
+                    if (!(t1 >= 0.0f)) c1 = 0.0f;
+                    if (!(t2 >= 0.0f)) c2 = 0.0f;
+                    if (c1 == 0.0f) wf.rayHit[slot] = make_int4(-1, 0, 0, 0); // never cast: "something else is nearest"
+                    if (c2 == 0.0f) wf.rayHit[cap + slot] = make_int4(-1, 0, 0, 0);
+                }
+                outO[slot] = make_float4(o2.x, o2.y, o2.z, c1);
+                outD[slot] = make_float4(T.wi1.x, T.wi1.y, T.wi1.z, t1);
+                outO[cap + slot] = make_float4(o2.x, o2.y, o2.z, c2);
+                outD[cap + slot] = make_float4(T.wi2.x, T.wi2.y, T.wi2.z, t2);
             }
+            wf.betaOld[pid] = make_float4(beta.x, beta.y, beta.z, __int_as_float(li));
+            f3 wi;
+            const bool alive = continuePath(c, bounce, SI.normal, m, dir, beta, wi);
+            outO[2 * cap + slot] = make_float4(o2.x, o2.y, o2.z, alive ? 1.0f : 0.0f);
+            outD[2 * cap + slot] = make_float4(wi.x, wi.y, wi.z, 0.0f);
+            wf.L_seed[pid] = make_float4(L.x, L.y, L.z, __int_as_float(c.seed));
+            wf.beta[pid] = make_float4(beta.x, beta.y, beta.z, __int_as_float(WF_FLAG_PENDING | (alive ? 0 : WF_FLAG_ENDED)));
+            if (wantStats) wf.pathStats[pid] = stats;
+            qout[slot] = pid;
         }
     }
     if (!(p.flags & RT_FLAG_NO_COUNTERS)) waveAdd(&counterShard(counters)->shaded_hits, shaded);
