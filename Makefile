@@ -16,7 +16,7 @@ HIPCC   ?= /opt/rocm/bin/hipcc
 
 HOSTFLAGS := -std=c++17 -O2 -fPIC -ffp-contract=off -Wall -Wno-unused-function -I$(ROOT)/include
 HIPFLAGS  := --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -Wall -Wno-unused-function \
-             -I$(ROOT)/include
+             -I$(ROOT)/include $(EXTRA_HIPFLAGS)
 ORCFLAGS  := -std=c11 -O2 -fPIC -ffp-contract=off -fno-fast-math -fopenmp -Wall -Wno-unused-function \
              -I$(ROOT)/include
 
