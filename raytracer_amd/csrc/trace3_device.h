@@ -267,6 +267,32 @@ __device__ __forceinline__ void loadNode(const RtScene &sc, int node, float4 &b0
     }
 }
 
+// The same fetch with the case decided at compile time, for the kernel whose walk is one long chain of dependent
+// steps (the wavefront extend kernel): NODES_PACKED_LDS = packed records, the whole node array in LDS (the named
+// scenes); NODES_PACKED = packed records, a prefix in LDS; NODES_ANY = whatever the scene has.  A step of the general
+// form spends more cycles in its branches than in the box test.
+enum { NODES_ANY = 0, NODES_PACKED = 1, NODES_PACKED_LDS = 2 };
+template <int MODE>
+__device__ __forceinline__ void loadNodeT(const RtScene &sc, int node, float4 &b0, float4 &b1, NodeLinks &k) {
+    if (MODE == NODES_ANY) {
+        loadNode(sc, node, b0, b1, k);
+        return;
+    }
+    if (MODE == NODES_PACKED_LDS || node < sc.cacheNodes) {
+        b0 = rtLdsNodes[2 * node];
+        b1 = rtLdsNodes[2 * node + 1];
+    } else {
+        b0 = sc.boxes[2 * node];
+        b1 = sc.boxes[2 * node + 1];
+    }
+    const int w0 = __float_as_int(b0.w), w1 = __float_as_int(b1.w);
+    const bool leaf = w1 < 0;
+    k.missNext = w0;
+    k.hitNext = leaf ? w0 : w1;
+    k.leafFirst = w1 & 0x03FFFFFF;
+    k.leafCount = leaf ? ((w1 >> 26) & 31) + 1 : 0;
+}
+
 // ---------------------------------------------------------------- traversal
 // intersectGeometry's loop (trace3.cs:226-269) + intersectTriangles (:172-186).
 // Returns false when the MAX_FOLLOWS abort was taken (trace3.cs:228-234).

@@ -383,6 +383,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // coalescing in the vector L1 costs more than the idle lanes did.  Inside, the walk is the same "while-while" as traverse() in trace3_device.h —
 // per ray, node visits and triangle tests happen in the reference's order — kept as resumable state.
 
+#ifdef RT_WAVE_TRACE
+// Development aid (make hip EXTRA_HIPFLAGS=-DRT_WAVE_TRACE, scripts/wave_trace.py): per-wave timeline of the extend kernel.
+__device__ long long rtWaveTrace[8][8192][16];
+extern "C" int rt_debug_wave_trace(void *dst, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(rtWaveTrace), bytes < sizeof(rtWaveTrace) ? bytes : sizeof(rtWaveTrace));
+}
+#define WT(...) __VA_ARGS__
+#else
+#define WT(...)
+#endif
 struct WaveShare { // phase-2 exchange area of one wave (4.75 KB)
     unsigned char owner[2048]; // pair index -> lane that owns the ray (64 lanes x at most 32 triangles)
     int first[64];
@@ -391,6 +401,7 @@ struct WaveShare { // phase-2 exchange area of one wave (4.75 KB)
     unsigned long long key[64];
 };
 
+template <int NODES>
 __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams p, WfBuffers wf, int stage,
                                                            int refillLanes, RtCountersDev *counters) {
     const int n = min(wf.counts[stage], wf.capacity);
@@ -429,23 +440,38 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     float nearest = 0.0f, hitT = 0.0f, hitU = 0.0f, hitV = 0.0f;
     // totals for the global counters
     unsigned cRays = 0, cVisits = 0, cTests = 0;
-    bool exhausted = total <= 0;
     // The queue cursor is one word shared by every wave of the launch, and atomics on one address retire at only
     // ~90 per microsecond on this part, so a wave takes a chunk of the queue per atomic (several refills' worth)
     // and hands it out to its lanes locally.  The chunk shrinks with the queue so that the tail stays balanced.
+    // Every wave's FIRST chunk is its own by position (wave w takes chunk w) and the cursor only hands out what
+    // lies beyond those: 4096 waves asking the cursor at once at the start of a launch queued for ~45 us, which
+    // was a third of a sparse launch (measured per wave with RT_WAVE_TRACE).
     int chunk = (int)min((long long)p.extendChunk, (long long)total / ((long long)residentWaves * 4));
     chunk = max(raysPerWave, chunk - chunk % raysPerWave);
-    int chunkNext = 0, chunkEnd = 0; // this wave's current piece of the queue: [chunkNext, chunkEnd)
+    const long long staticEnd = (long long)residentWaves * chunk; // the cursor counts from here
+    const long long myFirst = (long long)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * chunk;
+    // this wave's current piece of the queue: [chunkNext, chunkEnd)
+    int chunkNext = (int)min(myFirst, (long long)total), chunkEnd = (int)min(myFirst + chunk, (long long)total);
+    bool exhausted = total <= 0 || chunkNext >= total;
+    WT(const long long wt0 = wall_clock64(); const long long wc0 = clock64();
+       long long wtRefill = 0, wtWalkC = 0, wtSetup = 0, wtRounds = 0, wtFinish = 0, wtTail = 0;
+       int wtOuter = 0, wtCoop = 0, wtPairs = 0, wtWalk = 0, wtRetest = 0;)
 
     for (;;) {
+        WT(const long long c0 = clock64();)
         const unsigned long long idle = __ballot(!active && rayLane);
         const unsigned long long laneMask = raysPerWave >= 64 ? ~0ull : ((1ull << raysPerWave) - 1ull);
         if (!exhausted && (idle == laneMask || __popcll(idle) >= refillLanes)) {
             if (chunkNext >= chunkEnd) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(cursor, chunk);
-                chunkNext = __shfl(base, 0, 64);
-                chunkEnd = min(chunkNext + chunk, total);
+                if (staticEnd >= (long long)total) { // the chunks given out by position covered the whole queue
+                    chunkNext = chunkEnd = total;
+                } else {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(cursor, chunk);
+                    const long long at = staticEnd + (long long)__shfl(base, 0, 64);
+                    chunkNext = (int)min(at, (long long)total);
+                    chunkEnd = (int)min(at + chunk, (long long)total);
+                }
             }
             const int want = min(__popcll(idle), max(chunkEnd - chunkNext, 0));
             const int base = chunkNext;
@@ -485,6 +511,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             if (exhausted) break;
             continue;
         }
+        WT(wtOuter++; const int wtIt0 = iterations; const long long c1 = clock64(); wtRefill += c1 - c0;)
 
         // phase 1: walk nodes until this lane holds a leaf it entered, or has no node left
         int leafFirst = 0, leafCount = 0;
@@ -498,7 +525,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             }
             float4 b0, b1;
             NodeLinks k;
-            loadNode(sc, next, b0, b1, k);
+            loadNodeT<NODES>(sc, next, b0, b1, k);
             const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
                         m1z = (b0.z - origin.z) * invdir.z;
             const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
@@ -514,6 +541,11 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 next = k.hitNext;
             }
         }
+        WT({
+            int d = active ? iterations - wtIt0 : 0;
+            for (int o = 32; o; o >>= 1) d = max(d, __shfl_xor(d, o, 64));
+            wtWalk += d;
+        } const long long c2 = clock64(); wtWalkC += c2 - c1;)
         // phase 2: the leaves' triangles (geometry.glsl:31-51, trace3.cs:172-186), shared out over the wave.
         // Lanes hold leaves of 1..32 triangles (or none); testing "my leaf" lane by lane leaves most lanes idle
         // (measured: 38 % of the lanes active on room.obj, 20 % on scene.obj, and the kernel is VALU-issue
@@ -526,6 +558,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             const int incl = waveInclusiveScan(cnt);
             const int totalTests = __builtin_amdgcn_readlane(incl, 63);
             if (totalTests > 0) {
+                WT(wtCoop++; wtPairs += totalTests;)
                 const int excl = incl - cnt;
                 ws->first[lane] = leafFirst - excl; // triangle of pair g is first[owner] + g
                 ws->ro[lane] = make_float4(origin.x, origin.y, origin.z, nearest);
@@ -535,6 +568,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                WT(const long long c3 = clock64(); wtSetup += c3 - c2;)
                 // rounds of 64 pairs; the triangle of the next round is requested before this round's is tested
                 int g = lane, o = 0, tri = 0;
                 float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
@@ -573,6 +607,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                WT(const long long c4 = clock64(); wtRounds += c4 - c3;)
                 if (cnt > 0) {
                     const unsigned long long key = ws->key[lane];
                     if (key != ~0ull) { // the owner repeats the winning test: same arithmetic, same t, u, v
@@ -583,8 +618,10 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                     tests += (unsigned)cnt;
                 }
                 __builtin_amdgcn_wave_barrier();
+                WT(wtRetest += __any(cnt > 0 && ws->key[lane] != ~0ull) ? 1 : 0; wtFinish += clock64() - c4;)
             }
         }
+        WT(const long long c5 = clock64();)
         if (active && leafCount > 0) {
             if (!coop) { // full waves: every lane tests its own leaf, four triangles per batch of loads
                 testLeaf<false>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
@@ -601,7 +638,18 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             cTests += tests;
             active = false;
         }
+        WT(wtTail += clock64() - c5;)
     }
+    WT({
+        int r = (int)cRays;
+        for (int o = 32; o; o >>= 1) r += __shfl_xor(r, o, 64);
+        if (lane == 0 && stage < 8) {
+            long long *o = rtWaveTrace[stage][min((int)(blockIdx.x * 4 + (threadIdx.x >> 6)), 8191)];
+            o[0] = wt0; o[1] = wall_clock64(); o[2] = r; o[3] = wtOuter; o[4] = wtCoop; o[5] = wtPairs; o[6] = wtWalk;
+            o[7] = raysPerWave; o[8] = clock64() - wc0; o[9] = wtRefill; o[10] = wtWalkC; o[11] = wtSetup; o[12] = wtRounds;
+            o[13] = wtFinish; o[14] = wtTail; o[15] = wtRetest;
+        }
+    })
     PathCtx c = makeCtx(p, 0, 0, 0, 0);
     c.rays = cRays;
     c.visits = cVisits;
@@ -663,9 +711,13 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, false);
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
     const int logicBlocks = 256 * 4, extendBlocks = 256 * p.extendBlocksPerCU;
+    // the walk's node fetch is chosen here, once per launch (trace3_device.h: loadNodeT)
+    auto extendKernel = !sc.packedLeaves ? rt_wf_extend_kernel<NODES_ANY>
+                        : scExtend.cacheNodes >= sc.numNodes ? rt_wf_extend_kernel<NODES_PACKED_LDS>
+                                                             : rt_wf_extend_kernel<NODES_PACKED>;
     if (p.primaryViaExtend) {
         if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, true);
-        hipLaunchKernelGGL(rt_wf_extend_kernel, dim3(extendBlocks), dim3(256), extendLds, stream, scExtend, p, wf, 0,
+        hipLaunchKernelGGL(extendKernel, dim3(extendBlocks), dim3(256), extendLds, stream, scExtend, p, wf, 0,
                            p.refillLanes, counters);
         if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, false);
     }
@@ -675,7 +727,7 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
         if (prof) rtMarkKernel(prof, RT_TIME_WF_LOGIC, false);
         if (b < p.maxBounces) {
             if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, true);
-            hipLaunchKernelGGL(rt_wf_extend_kernel, dim3(extendBlocks), dim3(256), extendLds, stream, scExtend, p, wf, b + 1,
+            hipLaunchKernelGGL(extendKernel, dim3(extendBlocks), dim3(256), extendLds, stream, scExtend, p, wf, b + 1,
                                p.refillLanes, counters);
             if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, false);
         }
