@@ -68,7 +68,7 @@ struct rt_ctx {
     int tuneRefillLanes = 64, tuneExtendBlocks = 4; // development knobs: RT_WF_REFILL, RT_WF_BLOCKS
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
     int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 1, tuneChunk = 64, tunePrimaryBlocks = 32, tunePrimaryVia = -1;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
-    int tuneCacheNodes = 640;                        // RT_WF_CACHE_NODES: 20 KB + 19 KB of wave scratch per block, 4 blocks per CU
+    int tuneCacheNodes = 896;                        // RT_WF_CACHE_NODES: 28 KB + 12 KB of wave scratch per block, 4 blocks per CU
 
     DevBuf counters;
     bool profile = false;

@@ -393,12 +393,13 @@ extern "C" int rt_debug_wave_trace(void *dst, size_t bytes) {
 #else
 #define WT(...)
 #endif
-struct WaveShare { // phase-2 exchange area of one wave (4.75 KB)
-    unsigned char owner[2048]; // pair index -> lane that owns the ray (64 lanes x at most 32 triangles)
-    int first[64];
-    float4 ro[64]; // origin, w = nearest
+struct WaveShare { // phase-2 exchange area of one wave (3 KB); first/ro/rd/key are indexed by the RANK of the ray
+                   // among the lanes that hold a leaf this round
+    unsigned long long heads[32]; // bit g of the 2048-bit string: pair g is the first pair of its ray (zero between rounds)
+    int first[64];                // triangle of pair g = first[rank] + g
+    float4 ro[64];                // origin, w = nearest
     float4 rd[64];
-    unsigned long long key[64];
+    unsigned long long key[64];   // closest accepted hit so far: (bits(t), triangle)
 };
 
 template <int NODES>
@@ -429,6 +430,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     fillNodeCache(sc);
     // per-wave scratch behind the node cache
     WaveShare *ws = reinterpret_cast<WaveShare *>(rtLdsNodes + 2 * sc.cacheNodes) + (threadIdx.x >> 6);
+    if (lane < 32) ws->heads[lane] = 0ull;
 
     // per-lane ray state
     bool active = false;
@@ -555,25 +557,35 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         // smallest t below the ray's current nearest (strict `<`, trace3.cs:177).
         if (coop) {
             const int cnt = (active && leafCount > 0) ? leafCount : 0;
+            const unsigned long long holders = __ballot(cnt > 0);
             const int incl = waveInclusiveScan(cnt);
             const int totalTests = __builtin_amdgcn_readlane(incl, 63);
             if (totalTests > 0) {
                 WT(wtCoop++; wtPairs += totalTests;)
+                // Pairs are numbered ray after ray (g = exclusive prefix of the leaf sizes + k).  Which ray pair g
+                // belongs to is found from a bit string with a one at every ray's first pair: the number of ones
+                // at or below g, minus one, is the rank of the ray among the leaf-holding lanes.
                 const int excl = incl - cnt;
-                ws->first[lane] = leafFirst - excl; // triangle of pair g is first[owner] + g
-                ws->ro[lane] = make_float4(origin.x, origin.y, origin.z, nearest);
-                ws->rd[lane] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-                ws->key[lane] = ~0ull;
-                for (int k = 0; k < cnt; ++k) ws->owner[excl + k] = (unsigned char)lane; // pair -> owning lane
+                const int rank = __popcll(holders & lanesBelow);
+                if (cnt > 0) {
+                    ws->first[rank] = leafFirst - excl;
+                    ws->ro[rank] = make_float4(origin.x, origin.y, origin.z, nearest);
+                    ws->rd[rank] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+                    ws->key[rank] = ~0ull;
+                    atomicOr(&ws->heads[excl >> 6], 1ull << (excl & 63));
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 WT(const long long c3 = clock64(); wtSetup += c3 - c2;)
                 // rounds of 64 pairs; the triangle of the next round is requested before this round's is tested
+                const unsigned long long atOrBelow = (2ull << lane) - 1ull;
+                int rankBase = -1; // rank of the last ray that starts before this round
+                unsigned long long heads = ws->heads[0];
                 int g = lane, o = 0, tri = 0;
                 float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
                 if (g < totalTests) {
-                    o = ws->owner[g];
+                    o = rankBase + __popcll(heads & atOrBelow);
                     tri = ws->first[o] + g;
                     a0 = sc.tris48[3 * tri];
                     a1 = sc.tris48[3 * tri + 1];
@@ -583,8 +595,10 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                     const int gn = g + 64;
                     int on = 0, trin = 0;
                     float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+                    rankBase += __popcll(heads);
+                    if (base + 64 < totalTests) heads = ws->heads[(base >> 6) + 1];
                     if (gn < totalTests) {
-                        on = ws->owner[gn];
+                        on = rankBase + __popcll(heads & atOrBelow);
                         trin = ws->first[on] + gn;
                         n0 = sc.tris48[3 * trin];
                         n1 = sc.tris48[3 * trin + 1];
@@ -604,12 +618,13 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                     g = gn; o = on; tri = trin;
                     a0 = n0; a1 = n1; a2 = n2;
                 }
+                if (lane * 64 < totalTests) ws->heads[lane] = 0ull; // leave the bit string clear for the next round
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 WT(const long long c4 = clock64(); wtRounds += c4 - c3;)
                 if (cnt > 0) {
-                    const unsigned long long key = ws->key[lane];
+                    const unsigned long long key = ws->key[rank];
                     if (key != ~0ull) { // the owner repeats the winning test: same arithmetic, same t, u, v
                         const int wtri = (int)(unsigned)(key & 0xFFFFFFFFull);
                         testTriangle<false>(sc.tris48[3 * wtri], sc.tris48[3 * wtri + 1], sc.tris48[3 * wtri + 2], wtri, origin,
@@ -618,7 +633,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                     tests += (unsigned)cnt;
                 }
                 __builtin_amdgcn_wave_barrier();
-                WT(wtRetest += __any(cnt > 0 && ws->key[lane] != ~0ull) ? 1 : 0; wtFinish += clock64() - c4;)
+                WT(wtRetest += __any(cnt > 0 && ws->key[rank] != ~0ull) ? 1 : 0; wtFinish += clock64() - c4;)
             }
         }
         WT(const long long c5 = clock64();)
