@@ -296,6 +296,7 @@ __device__ __forceinline__ void loadNodeT(const RtScene &sc, int node, float4 &b
 // ---------------------------------------------------------------- traversal
 // intersectGeometry's loop (trace3.cs:226-269) + intersectTriangles (:172-186).
 // Returns false when the MAX_FOLLOWS abort was taken (trace3.cs:228-234).
+template <int NODES = NODES_ANY>
 __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origin, f3 dir, f3 invdir, Hit &hit) {
     // "while-while" form: every lane first walks nodes until it holds a leaf whose box it entered
     // (or runs out of nodes), then the wave tests leaf triangles together.  Per lane the sequence of
@@ -321,7 +322,7 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
             }
             float4 b0, b1;
             NodeLinks k;
-            loadNode(sc, next, b0, b1, k);
+            loadNodeT<NODES>(sc, next, b0, b1, k);
             // intersectBox, geometry.glsl:66-76
             const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
                         m1z = (b0.z - origin.z) * invdir.z;

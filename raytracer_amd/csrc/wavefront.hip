@@ -54,6 +54,16 @@ __device__ __forceinline__ int waveInclusiveScan(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
     return v;
 }
+// Largest value of the wave (values >= 0), by the same moves; lane 63 holds it.
+__device__ __forceinline__ int waveMaxNonNegative(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
 __device__ __forceinline__ PathCtx makeCtx(const WfParams &p, int x, int y, int sample, int seed) {
     PathCtx c;
@@ -84,6 +94,7 @@ __device__ __forceinline__ void flushCounters(const WfParams &p, RtCountersDev *
 } // namespace
 
 // ------------------------------------------------------------------------------------------ primary
+template <int NODES>
 __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
                                                             rt_rect tile, int tilesX, int tilesY, int xcdRemap,
                                                             int logicalBlocks, RtCountersDev *counters) {
@@ -143,7 +154,13 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
     // the caches; rays that miss the root box finish here as before (one node visit).
     const bool defer = p.primaryViaExtend && entersScene;
     if (active) {
-        if (!defer) traverse(sc, c, ld3(p.eye), dir, invdir, h);
+        if (!entersScene) { // the walk would stop at the root, which was tested above: one ray, one node visit
+            c.lastIterations = 1;
+            c.rays = 1;
+            c.visits = 1;
+        } else if (!defer) { // (the LDS copy of the nodes exists: a lane of this block enters the scene)
+            traverse<NODES>(sc, c, ld3(p.eye), dir, invdir, h);
+        }
         const size_t pix = (size_t)y * W + x;
         if ((p.flags & RT_FLAG_AUX) && !defer) {
             img.tridx[pix] = h.tridx;
@@ -425,7 +442,8 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     while (raysPerWave > 8 && (long long)(raysPerWave / 2) * residentWaves * p.extendFill >= total) raysPerWave >>= 1;
     if (p.extendRaysPerWave > 0) raysPerWave = p.extendRaysPerWave;
     if (!sc.packedLeaves) raysPerWave = 64; // the pair list below is sized for leaves of at most 32 triangles
-    const bool coop = sc.packedLeaves && (raysPerWave < 64 || p.extendCoop > 0);
+    // 0: every lane tests its own leaf; 1: the wave shares the tests out (phase 2 below); 2: decided round by round
+    const int coopMode = !sc.packedLeaves ? 0 : raysPerWave < 64 ? 1 : p.extendCoop;
     const bool rayLane = lane < raysPerWave;
     fillNodeCache(sc);
     // per-wave scratch behind the node cache
@@ -555,12 +573,18 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         // round, and the closest hit per ray is reduced with an LDS 64-bit atomic min on (t, triangle index).
         // That is the reference's result: it keeps the first triangle in index order among those with the
         // smallest t below the ray's current nearest (strict `<`, trace3.cs:177).
-        if (coop) {
+        bool shared = false;
+        if (coopMode != 0) {
             const int cnt = (active && leafCount > 0) ? leafCount : 0;
             const unsigned long long holders = __ballot(cnt > 0);
             const int incl = waveInclusiveScan(cnt);
             const int totalTests = __builtin_amdgcn_readlane(incl, 63);
-            if (totalTests > 0) {
+            shared = totalTests > 0;
+            // Full waves of an L2-resident scene: sharing pays when the leaves are few or uneven (lane by lane the
+            // wave takes as long as its largest leaf), not when every lane holds a leaf of similar size.
+            if (shared && coopMode == 2)
+                shared = ((totalTests + 63) >> 6) * p.coopA + p.coopB < 4 * waveMaxNonNegative(cnt);
+            if (shared) {
                 WT(wtCoop++; wtPairs += totalTests;)
                 // Pairs are numbered ray after ray (g = exclusive prefix of the leaf sizes + k).  Which ray pair g
                 // belongs to is found from a bit string with a one at every ray's first pair: the number of ones
@@ -638,7 +662,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         }
         WT(const long long c5 = clock64();)
         if (active && leafCount > 0) {
-            if (!coop) { // full waves: every lane tests its own leaf, four triangles per batch of loads
+            if (!shared) { // every lane tests its own leaf, four triangles per batch of loads
                 testLeaf<false>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
                 tests += (unsigned)leafCount;
             }
@@ -721,7 +745,10 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     scExtend.cacheNodes = sc.packedLeaves ? std::max(0, std::min(sc.numNodes, p.extendCacheNodes)) : 0;
     const size_t extendLds = (size_t)scExtend.cacheNodes * 32 + 4 * sizeof(WaveShare);
     const int primaryBlocks = std::min(nblocks, 256 * p.primaryBlocksPerCU);
-    hipLaunchKernelGGL(rt_wf_primary_kernel, dim3(primaryBlocks), dim3(256), (size_t)scPrimary.cacheNodes * 32, stream,
+    auto primaryKernel = !sc.packedLeaves ? rt_wf_primary_kernel<NODES_ANY>
+                         : (scPrimary.cacheNodes >= sc.numNodes && sc.numNodes > 0) ? rt_wf_primary_kernel<NODES_PACKED_LDS>
+                                                                                    : rt_wf_primary_kernel<NODES_PACKED>;
+    hipLaunchKernelGGL(primaryKernel, dim3(primaryBlocks), dim3(256), (size_t)scPrimary.cacheNodes * 32, stream,
                        scPrimary, img, p, wf, tile, tilesX, tilesY, xcdRemap, nblocks, counters);
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, false);
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
