@@ -8,6 +8,15 @@ usage: python scripts/summarize_profile.py r01c r01_final"""
 import collections, csv, glob, json, os, sys
 
 tag, name = sys.argv[1], sys.argv[2]
+
+
+def kname(full):
+    """'void rt_wf_extend_kernel<2>(RtScene, ...)' -> 'rt_wf_extend_kernel' (template variants are summed)."""
+    k = full.split("(")[0].strip()
+    if k.startswith("void "):
+        k = k[5:]
+    return k.split("<")[0]
+
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -19,14 +28,13 @@ if stats:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ns", "average_ns", "percentage", "min_ns", "max_ns"])
         for r in rows:
-            k = r["Name"].split("(")[0]
-            w.writerow([k, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+            w.writerow([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
     print("kernel stats:", len(rows), "kernels")
 
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
+        k = (kname(r["Kernel_Name"]), r["Counter_Name"])
         agg[k][0] += float(r["Counter_Value"])
         agg[k][1] += 1
 with open(os.path.join(dst, f"{name}_pmc_summary.csv"), "w", newline="") as f:
