@@ -67,8 +67,9 @@ struct rt_ctx {
     size_t wfCapacity = 0, wfRadianceSlots = 0;
     int tuneRefillLanes = 64, tuneExtendBlocks = 4; // development knobs: RT_WF_REFILL, RT_WF_BLOCKS
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
+    int tuneMinRays = 4;                             // RT_WF_MIN_RAYS: floor of the rays-per-wave rule
     int tuneCoopA = 8, tuneCoopB = 12;               // RT_WF_COOP_A / _B: the per-round rule of WfParams::coopA
-    int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 1, tuneChunk = 64, tunePrimaryBlocks = 32, tunePrimaryVia = -1;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
+    int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 2, tuneChunk = 64, tunePrimaryBlocks = 32, tunePrimaryVia = -1;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
     int tuneCacheNodes = 896;                        // RT_WF_CACHE_NODES: 28 KB + 12 KB of wave scratch per block, 4 blocks per CU
 
     DevBuf counters;
@@ -266,6 +267,7 @@ int rt_create(int device_id, rt_ctx **out) {
     if (const char *e = std::getenv("RT_WF_PRIMARY_VIA_EXTEND")) c->tunePrimaryVia = std::atoi(e);
     if (const char *e = std::getenv("RT_WF_CHUNK")) c->tuneChunk = std::max(8, std::min(65536, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_COOP")) c->tuneCoop = std::atoi(e);
+    if (const char *e = std::getenv("RT_WF_MIN_RAYS")) c->tuneMinRays = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_COOP_A")) c->tuneCoopA = std::atoi(e);
     if (const char *e = std::getenv("RT_WF_COOP_B")) c->tuneCoopB = std::atoi(e);
     if (const char *e = std::getenv("RT_WF_BLOCKS")) c->tuneExtendBlocks = std::max(1, std::min(8, std::atoi(e)));
@@ -601,6 +603,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         wp.extendCacheNodes = c->tuneCacheNodes;
         wp.extendRaysPerWave = c->tuneRaysPerWave;
         wp.extendFill = c->tuneFill;
+        wp.extendMinRays = c->tuneMinRays;
         wp.extendChunk = c->tuneChunk;
         // full waves test their leaves cooperatively when the triangles do not fit the L2s (measured on MI355X: the
         // coalesced triangle reads of that scheme win on the 1.7 M-triangle lattice, 3.66 -> 3.28 ms, and lose to

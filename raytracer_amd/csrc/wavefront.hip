@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     // cooperatively (phase 2 below), which keeps all 64 lanes busy there whatever the number of rays.
     const int residentWaves = (int)gridDim.x * (int)(blockDim.x >> 6);
     int raysPerWave = 64;
-    while (raysPerWave > 8 && (long long)(raysPerWave / 2) * residentWaves * p.extendFill >= total) raysPerWave >>= 1;
+    while (raysPerWave > max(p.extendMinRays, 1) && (long long)(raysPerWave / 2) * residentWaves * p.extendFill >= total) raysPerWave >>= 1;
     if (p.extendRaysPerWave > 0) raysPerWave = p.extendRaysPerWave;
     if (!sc.packedLeaves) raysPerWave = 64; // the pair list below is sized for leaves of at most 32 triangles
     // 0: every lane tests its own leaf; 1: the wave shares the tests out (phase 2 below); 2: decided round by round

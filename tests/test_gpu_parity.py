@@ -307,3 +307,46 @@ def test_fast_shadows_flag_gives_the_same_picture(ctx, scene, w, h, spp, mb):
     assert same > 0.999, same
     assert_radiance_close(ref["color"], fast["color"], f"fast shadows {scene}")
     assert (c1.rays - c1.paths) < 0.8 * (c0.rays - c0.paths) and c1.node_visits < c0.node_visits  # secondary rays
+
+
+class _CustomWorkload:
+    """room.obj plus extra triangle records, framed by the reference camera."""
+
+    def __init__(self, extra, width, height):
+        self.width, self.height = width, height
+        self.scene = hostlib.Scene(assets.path("room.obj"))
+        self.scene.add_triangles(extra)
+        self.scene.build(with_qtable=False)
+        self.info = self.scene.info()
+        self.buffers = {s: self.scene.buffer(s) for s in hostlib.ALL_SLOTS}
+        self.camera = dict(hostlib.REFERENCE_CAMERA)
+        self.rays = hostlib.camera_rays(width=width, height=height, **self.camera)
+        self.eye = np.array(self.camera["eye"], np.float32)
+        self.num_emitters = self.info.num_emitters
+
+
+def test_leaf_of_more_than_32_triangles_takes_the_general_node_path(ctx):
+    """40 coincident triangles cannot be split, so the builder leaves them in one leaf (the reference's builder
+    recurses forever on them, BVH.cpp:84-149).  A leaf of more than 32 triangles does not fit the packed node
+    record, so every kernel falls back to the general node fetch and lane-by-lane leaf tests: same bar."""
+    rec = np.zeros(40, hostlib.TRI_DTYPE)
+    rec["v0"], rec["v1"], rec["v2"] = [-0.6, 2.4, 0.5], [0.6, 2.4, 0.5], [0.0, 3.4, 0.5]   # faces the camera
+    rec["n0"] = rec["n1"] = rec["n2"] = [0, 0, 1]
+    rec["mtlIndex"] = 0
+    wl = _CustomWorkload(rec, 200, 112)
+    assert wl.info.max_leaf_triangles == 40
+    got = render(ctx, wl, 2, 3)
+    ref = oracle_render(wl, 2, 3)
+    assert_ids_equal(got, ref)
+    stream = np.frombuffer(wl.buffers[4], hostlib.TRI_DTYPE)          # the builder reorders triangles leaf by leaf
+    mine = np.nonzero((stream["v0"] == np.float32([-0.6, 2.4, 0.5])).all(-1))[0]
+    assert len(mine) == 40 and mine.max() - mine.min() == 39           # one leaf, contiguous
+    hit = np.isin(got["tridx"], mine)
+    assert hit.mean() > 0.02                      # the stack of triangles is on screen ...
+    # ... and of 40 coincident candidates the first in stream order wins (strict `<`, trace3.cs:177)
+    assert np.unique(got["tridx"][hit]).tolist() == [int(mine.min())]
+    assert_radiance_close(ref["color"], got["color"], "leaf40")
+    # and both schedules agree bit for bit on this path too
+    pp = render(ctx, wl, 2, 3, flags=hiplib.FLAG_AUX | hiplib.FLAG_PIXEL_STATS | hiplib.FLAG_PER_PIXEL_KERNEL)
+    for k in ALL_IMAGES:
+        assert np.array_equal(got[k].view(np.uint8), pp[k].view(np.uint8)), k
