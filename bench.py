@@ -83,12 +83,20 @@ def main():
         a.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # RT_BENCH_COLLECTIVES=gloo is a rehearsal of the N > 1 code path on a one-GPU box: every rank uses device 0 and
+    # the strips travel through host memory.  The driver's runs use the default, RCCL ("nccl"), one GPU per rank.
+    rehearsal = os.environ.get("RT_BENCH_COLLECTIVES", "nccl") == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
 
     wl = workloads.Workload(a.scene, W, H)
     ctx = hiplib.Context(local_rank)
@@ -124,6 +132,16 @@ def main():
 
     cnt = ctx.counters()
     tm = ctx.timings()
+    # Strips overlap by the filter halo, so the rays the ranks traced add up to more than the frame has.  `value`
+    # counts the frame's own rays: every rank traces its strip once more WITHOUT the halo (outside the timed region;
+    # a pixel's rays do not depend on the tile it is traced in) and the strips partition the frame.
+    frame_rays = float(cnt.rays) / max(a.steps, 1)
+    if world > 1:
+        ctx.profile(False)
+        ctx.reset_counters()
+        backend.trace(frame.strip, 0)
+        ctx.sync()
+        frame_rays = float(ctx.counters().rays)
     # Opt-in extra, outside the measured value: the same frames with RT_FLAG_FAST_SHADOWS (not the reference's
     # algorithm: shadow rays that miss their light are not cast, the others stop at the first nearer hit).
     fast_ms = None
@@ -139,8 +157,8 @@ def main():
         backend.flags = 0
     K = hiplib
     local = torch.tensor([elapsed, float(cnt.rays), float(cnt.node_visits), float(cnt.tri_tests),
-                          float(cnt.shaded_hits), float(cnt.paths)] + [tm.ms[i] for i in range(8)],
-                         dtype=torch.float64, device=device)
+                          float(cnt.shaded_hits), float(cnt.paths)] + [tm.ms[i] for i in range(8)] + [frame_rays],
+                         dtype=torch.float64, device="cpu" if rehearsal else device)
     if dist is not None:
         tmax = local.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -157,8 +175,9 @@ def main():
         return
 
     rays, visits, tests, hits, paths = sums[1:6]
+    frame_rays = sums[14]
     ms_per_step = elapsed * 1e3 / a.steps
-    mrays = rays / elapsed / 1e6
+    mrays = frame_rays * a.steps / elapsed / 1e6
     # Roofline of the dominant kernel, per launch, from HIP events recorded on the kernel's own stream
     # (rt_profile).  The dominant kernel is whichever of the pipeline's kernels took most device time on
     # this rank; its algorithmic bytes follow SURVEY.md 8(d): 48 B per node visit + 48 B per triangle
@@ -204,13 +223,15 @@ def main():
         "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        **({"rehearsal": "gloo collectives, all ranks on GPU 0: not a measurement"} if rehearsal else {}),
         "config": {"workload": f"{a.scene}.obj {W}x{H} {a.spp}spp maxBounces {a.bounces} + {a.filter}-iteration "
                                f"a-trous filter, SURVEY 8(d) auto camera + harness quad light"
                                f" (BASELINE.json configs[2])",
                    "triangles": wl.info.num_triangles, "nodes": wl.info.num_nodes, "emitters": wl.num_emitters,
                    "schedule": "wavefront pipeline, samples of a frame traced concurrently (rt_trace_batch)",
                    "parallelism": f"{world} x screen-space row strips, halo {backend.halo} rows, gather to rank 0"},
-        "rays_per_frame": rays / a.steps, "node_visits_per_frame": visits / a.steps,
+        "rays_per_frame": frame_rays, "rays_traced_per_frame_incl_halo": rays / a.steps,
+        "node_visits_per_frame": visits / a.steps,
         "tri_tests_per_frame": tests / a.steps,
         "kernel_ms_per_frame_max_rank": {K.TIME_NAMES[i]: round(maxs[6 + i] / a.steps, 4) for i in range(8)
                                          if maxs[6 + i] > 0},

@@ -79,6 +79,7 @@ class TiledFrame:
         self.strip = (0, y0, width, y1)
         self.traced = grow_rect(self.strip, backend.halo, width, height)
         self.max_rows = -(-height // world)
+        self._pad = self._recv = None
 
     def render(self, frame=0):
         """Trace strip + halo, filter the strip.  No communication."""
@@ -94,9 +95,15 @@ class TiledFrame:
         if dist is None:
             import torch.distributed as dist
         mine = self.b.read_rect(self.result_image, self.strip)
-        pad = torch.zeros((self.max_rows, mine.shape[1]), dtype=torch.uint8, device=mine.device)
+        via_host = mine.is_cuda and dist.get_backend() == "gloo"  # rehearsal on a one-GPU box (bench.py)
+        if via_host:
+            mine = mine.cpu()
+        if self._pad is None or self._pad.shape[1] != mine.shape[1] or self._pad.device != mine.device:
+            # staging memory is allocated once: every frame re-uses it (rows beyond a short last strip stay zero)
+            self._pad = torch.zeros((self.max_rows, mine.shape[1]), dtype=torch.uint8, device=mine.device)
+            self._recv = [torch.empty_like(self._pad) for _ in range(self.world)] if self.rank == 0 else None
+        pad, recv = self._pad, self._recv
         pad[: mine.shape[0]] = mine
-        recv = [torch.empty_like(pad) for _ in range(self.world)] if self.rank == 0 else None
         dist.gather(pad, recv, dst=0)
         if pad.is_cuda:
             # the launcher copies on its own HIP stream: the collective (and the staging copy above) must have
@@ -105,5 +112,6 @@ class TiledFrame:
         if self.rank == 0:
             for r in range(1, self.world):
                 y0, y1 = strip_rows(self.height, self.world, r)
-                self.b.write_rect(self.result_image, (0, y0, self.width, y1), recv[r][: y1 - y0])
+                part = recv[r][: y1 - y0]
+                self.b.write_rect(self.result_image, (0, y0, self.width, y1), part.to(self.b.device) if via_host else part)
         return recv
