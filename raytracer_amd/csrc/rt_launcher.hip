@@ -67,6 +67,17 @@ struct rt_ctx {
     size_t wfCapacity = 0, wfRadianceSlots = 0;
     int tuneRefillLanes = 64, tuneExtendBlocks = 4; // development knobs: RT_WF_REFILL, RT_WF_BLOCKS
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
+    int tuneWalkStop = 0, tuneWalkMin = 0;           // RT_WF_WALK_STOP (eighths), RT_WF_WALK_MIN: 0 = by scene size (WfParams::walkStop)
+    // L2-resident scenes: whether full waves should cut their walk phases short depends on the scene (room.obj
+    // -9 %, scene.obj +10 %), so the first frames after a scene upload / resize time both settings and the
+    // launcher keeps the faster one.  The picture does not depend on it.
+    struct WalkTune {
+        int state = 0;        // 0 warm-up frame, 1 timing "walk to the end", 2 timing "stop early", 3 decided
+        bool pending = false; // walkEv[] of the frame being timed are recorded
+        float msWhole = 0.0f;
+        int choice = 8;       // walkStop in use once decided
+        hipEvent_t ev[2] = {nullptr, nullptr};
+    } walkTune;
     int tuneMinRays = 4;                             // RT_WF_MIN_RAYS: floor of the rays-per-wave rule
     int tuneCoopA = 8, tuneCoopB = 12;               // RT_WF_COOP_A / _B: the per-round rule of WfParams::coopA
     int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 2, tuneChunk = 64, tunePrimaryBlocks = 32, tunePrimaryVia = -1;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
@@ -267,6 +278,8 @@ int rt_create(int device_id, rt_ctx **out) {
     if (const char *e = std::getenv("RT_WF_PRIMARY_VIA_EXTEND")) c->tunePrimaryVia = std::atoi(e);
     if (const char *e = std::getenv("RT_WF_CHUNK")) c->tuneChunk = std::max(8, std::min(65536, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_COOP")) c->tuneCoop = std::atoi(e);
+    if (const char *e = std::getenv("RT_WF_WALK_STOP")) c->tuneWalkStop = std::max(0, std::min(8, std::atoi(e)));
+    if (const char *e = std::getenv("RT_WF_WALK_MIN")) c->tuneWalkMin = std::max(0, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_MIN_RAYS")) c->tuneMinRays = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_COOP_A")) c->tuneCoopA = std::atoi(e);
     if (const char *e = std::getenv("RT_WF_COOP_B")) c->tuneCoopB = std::atoi(e);
@@ -290,6 +303,8 @@ void rt_destroy(rt_ctx *c) {
         (void)hipEventDestroy(s.stop);
     }
     for (hipEvent_t e : c->eventPool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->walkTune.ev)
+        if (e) (void)hipEventDestroy(e);
     DevBuf *all[] = {&c->boxes, &c->leaves, &c->tris48, &c->tris128, &c->mtls, &c->emitters, &c->color, &c->normal,
                      &c->pos, &c->filt[0], &c->filt[1], &c->tridx, &c->visits, &c->stats, &c->ldr, &c->counters,
                      &c->wfQueue[0], &c->wfQueue[1], &c->wfCounts, &c->wfRadiance};
@@ -320,6 +335,8 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
     if (r) return r;
     switch (slot) {
     case RT_SLOT_NODES: {
+        c->walkTune.state = 0;
+        c->walkTune.pending = false;
         if (nbytes % sizeof(RtNode48)) return fail(c, RT_EINVAL, "rt_upload: node stream is not a multiple of 48 bytes");
         const size_t n = nbytes / sizeof(RtNode48);
         if (n == 0 || n > 0x7FFFFFFFu / 2) return fail(c, RT_EINVAL, "rt_upload: node count out of range");
@@ -456,6 +473,8 @@ int rt_resize(rt_ctx *c, int width, int height) {
         (r = ensure(c, c->filt[0], n * 8)) || (r = ensure(c, c->filt[1], n * 8)) || (r = ensure(c, c->tridx, n * 4)) ||
         (r = ensure(c, c->visits, n * 4)) || (r = ensure(c, c->stats, n * 16)) || (r = ensure(c, c->ldr, n * 4)))
         return r;
+    c->walkTune.state = 0;
+    c->walkTune.pending = false;
     c->width = width;
     c->height = height;
     return rt_clear(c);
@@ -604,6 +623,29 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         wp.extendRaysPerWave = c->tuneRaysPerWave;
         wp.extendFill = c->tuneFill;
         wp.extendMinRays = c->tuneMinRays;
+        // beyond the L2s every walk step is a trip to memory: stop the walk phase early at any wave width;
+        // L2-resident scenes: only while the wave is (nearly) full
+        const bool beyondL2 = hot > (size_t)3 * 1024 * 1024;
+        wp.walkStop = c->tuneWalkStop > 0 ? c->tuneWalkStop : (beyondL2 ? 4 : 8);
+        wp.walkMin = c->tuneWalkMin > 0 ? c->tuneWalkMin : (beyondL2 ? 1 : 40);
+        rt_ctx::WalkTune &wt = c->walkTune;
+        const bool tuning = c->tuneWalkStop == 0 && !beyondL2 && tilePixels * (size_t)n >= ((size_t)1 << 20);
+        if (tuning) {
+            if (wt.pending) { // the frame timed by the previous call (blocks only during the first three frames)
+                float ms = 0.0f;
+                HIP_TRY(c, hipEventSynchronize(wt.ev[1]));
+                HIP_TRY(c, hipEventElapsedTime(&ms, wt.ev[0], wt.ev[1]));
+                wt.pending = false;
+                if (wt.state == 1) {
+                    wt.msWhole = ms;
+                    wt.state = 2;
+                } else if (wt.state == 2) {
+                    wt.choice = ms < 0.97f * wt.msWhole ? 1 : 8;
+                    wt.state = 3;
+                }
+            }
+            wp.walkStop = wt.state == 2 ? 1 : wt.state == 3 ? wt.choice : 8;
+        }
         wp.extendChunk = c->tuneChunk;
         // full waves test their leaves cooperatively when the triangles do not fit the L2s (measured on MI355X: the
         // coalesced triangle reads of that scheme win on the 1.7 M-triangle lattice, 3.66 -> 3.28 ms, and lose to
@@ -618,10 +660,21 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             wp.s[k].oob1 = params[k].oobSeeds[1];
             wp.s[k].oob2 = params[k].oobSeeds[2];
         }
+        const bool timeIt = tuning && (wt.state == 1 || wt.state == 2);
+        if (timeIt) {
+            if (!wt.ev[0]) wt.ev[0] = takeEvent(c);
+            if (!wt.ev[1]) wt.ev[1] = takeEvent(c);
+            HIP_TRY(c, hipEventRecord(wt.ev[0], c->stream));
+        }
         SpanGuard span(c, TK_TRACE);
         hipError_t e = rtLaunchWavefront(sc, img, wp, wf, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream,
                                          c->profile ? c : nullptr);
         span.end();
+        if (timeIt) {
+            HIP_TRY(c, hipEventRecord(wt.ev[1], c->stream));
+            wt.pending = true;
+        }
+        if (tuning && wt.state == 0) wt.state = 1;
         if (e != hipSuccess) return hipFail(c, e, "wavefront launch");
         return RT_OK;
     }

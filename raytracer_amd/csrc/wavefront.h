@@ -21,6 +21,8 @@ struct WfParams {
     int extendRaysPerWave; // 0 = chosen per launch from the queue size; 8..64 forces it (development knob)
     int extendFill;        // rays-per-wave rule: halve while (rays/2) * resident waves * extendFill >= queued rays
     int extendMinRays;     // ... but not below this many rays per wave
+    int walkMin;           // ... if at least walkMin lanes are walking
+    int walkStop;          // extend: the node-walk phase of a round ends when walkStop/8 of the walking lanes hold a leaf (8: all)
     int extendChunk;       // most queue entries a wave takes with one atomic on the shared cursor
     int extendCoop;        // leaf tests of full waves: 0 lane by lane, 1 cooperative, 2 decided per round (see coopA / coopB)
     int coopA, coopB;      // a round is tested cooperatively when rounds_of_64_pairs * coopA + coopB < 4 * largest_leaf

@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     if (!sc.packedLeaves) raysPerWave = 64; // the pair list below is sized for leaves of at most 32 triangles
     // 0: every lane tests its own leaf; 1: the wave shares the tests out (phase 2 below); 2: decided round by round
     const int coopMode = !sc.packedLeaves ? 0 : raysPerWave < 64 ? 1 : p.extendCoop;
+    const int walkStop = coopMode == 0 ? 8 : p.walkStop; // see phase 1
     const bool rayLane = lane < raysPerWave;
     fillNodeCache(sc);
     // per-wave scratch behind the node cache
@@ -534,8 +535,19 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         WT(wtOuter++; const int wtIt0 = iterations; const long long c1 = clock64(); wtRefill += c1 - c0;)
 
         // phase 1: walk nodes until this lane holds a leaf it entered, or has no node left
+        // Incoherent rays differ widely in the number of steps to their next leaf, and a wave that waits for its
+        // last lane keeps a quarter of its lanes busy (measured on the 50 M-triangle scene).  With walkStop < 8 the
+        // phase ends as soon as walkStop/8 of the walking lanes hold a leaf; the others keep their place in the
+        // walk and go on in the next round.  Per lane nothing changes: same visits, same tests, same order.
         int leafFirst = 0, leafCount = 0;
-        while (active && next != -1 && leafCount == 0) {
+        int found = 0, stopAt = 64;
+        const int walking = walkStop < 8 ? __popcll(__ballot(active && next != -1)) : 0;
+        // L2-resident scenes (walkMin = 40): only (nearly) full waves stop early — a wave with few walking lanes is
+        // bounded by its longest ray, not by idle lanes — and whether that pays at all depends on the scene (the
+        // launcher times both, rt_launcher.hip).  Beyond the L2s every step is a trip to memory and stopping early
+        // pays at any width (walkMin = 1).
+        if (walkStop < 8 && walking >= p.walkMin) stopAt = max(1, (walking * walkStop) >> 3);
+        while (active && next != -1 && leafCount == 0 && found < stopAt) {
             iterations++;
             if (iterations > p.maxFollows) { // trace3.cs:228-234
                 hitTri = -1;
@@ -560,6 +572,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 leafCount = k.leafCount;
                 next = k.hitNext;
             }
+            if (walkStop < 8) found += __popcll(__ballot(leafCount > 0));
         }
         WT({
             int d = active ? iterations - wtIt0 : 0;
