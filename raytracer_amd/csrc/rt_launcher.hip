@@ -65,7 +65,7 @@ struct rt_ctx {
     // wavefront path tracer state (wavefront.h), grown on demand
     DevBuf wfState[8], wfRay[6], wfQueue[2], wfCounts, wfRadiance;
     size_t wfCapacity = 0, wfRadianceSlots = 0;
-    int tuneRefillLanes = 64, tuneExtendBlocks = 4; // development knobs: RT_WF_REFILL, RT_WF_BLOCKS
+    int tuneRefillLanes = 0, tuneExtendBlocks = 4;  // development knobs: RT_WF_REFILL (0: by scene size), RT_WF_BLOCKS
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
     int tuneWalkStop = 0, tuneWalkMin = 0;           // RT_WF_WALK_STOP (eighths), RT_WF_WALK_MIN: 0 = by scene size (WfParams::walkStop)
     // L2-resident scenes: whether full waves should cut their walk phases short depends on the scene (room.obj
@@ -615,7 +615,9 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         wp.maxFollows = p->maxFollows > 0 ? p->maxFollows : 1000;
         wp.flags = p->flags;
         wp.batch = n;
-        wp.refillLanes = c->tuneRefillLanes;
+        // a wave takes new rays when all its lanes are free (neighbouring rays stay together: vector-L1 locality) —
+        // or, when the scene is beyond the L2s and there is no locality to keep, as soon as half of them are
+        wp.refillLanes = c->tuneRefillLanes > 0 ? c->tuneRefillLanes : (hot > (size_t)3 * 1024 * 1024 ? 32 : 64);
         wp.extendBlocksPerCU = c->tuneExtendBlocks;
         wp.primaryBlocksPerCU = c->tunePrimaryBlocks;
         wp.primaryViaExtend = c->tunePrimaryVia >= 0 ? c->tunePrimaryVia : (hot > (size_t)3 * 1024 * 1024 ? 1 : 0);
@@ -626,7 +628,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         // beyond the L2s every walk step is a trip to memory: stop the walk phase early at any wave width;
         // L2-resident scenes: only while the wave is (nearly) full
         const bool beyondL2 = hot > (size_t)3 * 1024 * 1024;
-        wp.walkStop = c->tuneWalkStop > 0 ? c->tuneWalkStop : (beyondL2 ? 4 : 8);
+        wp.walkStop = c->tuneWalkStop > 0 ? c->tuneWalkStop : (beyondL2 ? 3 : 8);
         wp.walkMin = c->tuneWalkMin > 0 ? c->tuneWalkMin : (beyondL2 ? 1 : 40);
         rt_ctx::WalkTune &wt = c->walkTune;
         const bool tuning = c->tuneWalkStop == 0 && !beyondL2 && tilePixels * (size_t)n >= ((size_t)1 << 20);

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         WT(const long long c0 = clock64();)
         const unsigned long long idle = __ballot(!active && rayLane);
         const unsigned long long laneMask = raysPerWave >= 64 ? ~0ull : ((1ull << raysPerWave) - 1ull);
-        if (!exhausted && (idle == laneMask || __popcll(idle) >= refillLanes)) {
+        if (!exhausted && (idle == laneMask || __popcll(idle) * 64 >= refillLanes * raysPerWave)) { // refillLanes of 64
             if (chunkNext >= chunkEnd) {
                 if (staticEnd >= (long long)total) { // the chunks given out by position covered the whole queue
                     chunkNext = chunkEnd = total;
