@@ -59,27 +59,17 @@ __device__ __forceinline__ float random3(float a, float b, float c) { // random.
 
 // rand_seeds, trace3.cs:280; negative indices read the caller-supplied values (rt_launcher.h)
 __device__ __forceinline__ float seedAt(const PathCtx &c, int i) {
-    float r;
-    switch (i) {
-    case 0: r = 0.0f; break;
-    case 1: r = 1.1f; break;
-    case 2: r = 0.3f; break;
-    case 3: r = 3.3f; break;
-    case 4: r = 0.6f; break;
-    case 5: r = 4.5f; break;
-    case 6: r = 2.4f; break;
-    case 7: r = 0.1f; break;
-    case 8: r = 1.7f; break;
-    case 9: r = 4.7f; break;
-    case 10: r = 1.9f; break;
-    case 11: r = 2.6f; break;
-    case 12: r = 4.8f; break;
-    case -1: r = c.oob0; break;
-    case -2: r = c.oob1; break;
-    case -3: r = c.oob2; break;
-    default: r = 0.0f; break;
-    }
-    return r;
+    // A 16-entry table for i = -3 .. 12 (oob2, oob1, oob0, then rand_seeds[0..12] = 0.0 1.1 0.3 3.3 0.6 4.5 2.4 0.1 1.7 4.7
+    // 1.9 2.6 4.8), read by a four-level select on the bits of i + 3: the index differs from lane to lane, and as a
+    // `switch` this was a tree of divergent branches (about a hundred scalar instructions per random number).
+    const unsigned k = (unsigned)(i + 3);
+    const bool b0 = (k & 1u) != 0, b1 = (k & 2u) != 0, b2 = (k & 4u) != 0, b3 = (k & 8u) != 0;
+    const float e0 = b0 ? c.oob1 : c.oob2, e1 = b0 ? 0.0f : c.oob0, e2 = b0 ? 0.3f : 1.1f, e3 = b0 ? 0.6f : 3.3f,
+                e4 = b0 ? 2.4f : 4.5f, e5 = b0 ? 1.7f : 0.1f, e6 = b0 ? 1.9f : 4.7f, e7 = b0 ? 4.8f : 2.6f;
+    const float f0 = b1 ? e1 : e0, f1 = b1 ? e3 : e2, f2 = b1 ? e5 : e4, f3 = b1 ? e7 : e6;
+    const float g0 = b2 ? f1 : f0, g1 = b2 ? f3 : f2;
+    const float r = b3 ? g1 : g0;
+    return k < 16u ? r : 0.0f;
 }
 __device__ __forceinline__ float rnd(const PathCtx &c, int s, int idx) {
     return random3((float)(c.px + s), (float)(c.py + s), c.time + seedAt(c, idx));
