@@ -350,3 +350,30 @@ def test_leaf_of_more_than_32_triangles_takes_the_general_node_path(ctx):
     pp = render(ctx, wl, 2, 3, flags=hiplib.FLAG_AUX | hiplib.FLAG_PIXEL_STATS | hiplib.FLAG_PER_PIXEL_KERNEL)
     for k in ALL_IMAGES:
         assert np.array_equal(got[k].view(np.uint8), pp[k].view(np.uint8)), k
+
+
+def test_config4_size_eight_strips_equal_the_full_frame(ctx):
+    """BASELINE.json configs[3] at its full size (scene.obj 3840x2160, 16 spp, 5 filter passes) through the property
+    the 8-GPU decomposition rests on: each of the eight strips, traced with its halo and filtered on its own,
+    reproduces the rows of the frame rendered in one piece, bit for bit."""
+    from raytracer_amd import parallel
+    W, H, spp, iters, world = 3840, 2160, 16, 5, 8
+    wl = workloads.Workload("scene", W, H)
+    ctx.upload_scene(wl.buffers)
+    ctx.resize(W, H)
+    kw = dict(spp=spp, max_bounces=5, flags=0, num_emitters=wl.num_emitters)
+    ctx.trace_samples(wl.rays, wl.eye, **kw)
+    ctx.filter(iters)
+    full = ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16).copy()
+    full_color = ctx.readback(hiplib.IMAGE_COLOR).copy()
+    assert np.isfinite(full_color).all() and len(np.unique(full[..., :3])) > 1000
+    halo = hiplib.lib().rt_filter_halo(iters)
+    for rank in range(world):
+        y0, y1 = parallel.strip_rows(H, world, rank)
+        traced = parallel.grow_rect((0, y0, W, y1), halo, W, H)
+        ctx.clear()
+        ctx.write_image(hiplib.IMAGE_COLOR, np.full((H, W, 4), np.nan, np.float32))   # poison what this rank does not trace
+        ctx.trace_samples(wl.rays, wl.eye, rect=traced, **kw)
+        ctx.filter(iters, rect=(0, y0, W, y1))
+        part = ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16)
+        assert np.array_equal(part[y0:y1], full[y0:y1]), rank
