@@ -11,6 +11,8 @@ shadow), counted by the device counters the parity tests check.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--scene scene|room|...] [--size WxH]
   N > 1:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --scene lattice      SURVEY 8(d) config #5 (BASELINE.json configs[4]): 50.36 M triangles, 3840x2160,
+                                       1 spp, maxBounces 4, no filter, traversal cap lifted — the HBM-bound regime
 """
 import argparse
 import json
@@ -27,7 +29,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 VALU_PEAK_TOPS_NOFMA = 78.6  # 157.3 TFLOP/s fp32 vector counts an FMA as 2; parity mode issues no FMA
 
 
-def cpu_baseline(wl, spp, max_bounces, filter_iters):
+def cpu_baseline(wl, spp, max_bounces, filter_iters, max_follows=1000):
     """The CPU restatement (oracle/, kind "port") timed on this host's cores on one frame of the
     same workload, bounded to ~10-30 s: rows are sub-sampled if a first probe says it would take longer."""
     from oracle import orclib
@@ -38,12 +40,14 @@ def cpu_baseline(wl, spp, max_bounces, filter_iters):
     probe_rows = max(8, H // 32)
     y0 = (H - probe_rows) // 2
     t = time.time()
-    orclib.trace(sc, W, H, wl.rays, wl.eye, spp=1, max_bounces=max_bounces, rect=(0, y0, W, y0 + probe_rows))
+    orclib.trace(sc, W, H, wl.rays, wl.eye, spp=1, max_bounces=max_bounces, rect=(0, y0, W, y0 + probe_rows),
+                 max_follows=max_follows)
     per_row = (time.time() - t) / probe_rows
     rows = H if per_row * H * spp < 25.0 else max(probe_rows, int(25.0 / (per_row * spp)))
     y0 = (H - rows) // 2
     t = time.time()
-    o = orclib.trace(sc, W, H, wl.rays, wl.eye, spp=spp, max_bounces=max_bounces, rect=(0, y0, W, y0 + rows))
+    o = orclib.trace(sc, W, H, wl.rays, wl.eye, spp=spp, max_bounces=max_bounces, rect=(0, y0, W, y0 + rows),
+                     max_follows=max_follows)
     t_trace = time.time() - t
     rays = int(o["stats_sum"][..., 0].sum())
     t = time.time()
@@ -63,12 +67,20 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scene", default="scene")
-    ap.add_argument("--size", default="1920x1080")
-    ap.add_argument("--spp", type=int, default=4)
-    ap.add_argument("--bounces", type=int, default=5)
-    ap.add_argument("--filter", type=int, default=5)
+    ap.add_argument("--size", default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--bounces", type=int, default=None)
+    ap.add_argument("--filter", type=int, default=None)
+    ap.add_argument("--lattice", default="37x37x38", help="copies of suzanne.obj for --scene lattice")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
+    lattice = a.scene == "lattice"
+    # defaults: the metric configuration; for the lattice, config #5's
+    a.size = a.size or ("3840x2160" if lattice else "1920x1080")
+    a.spp = a.spp if a.spp is not None else (1 if lattice else 4)
+    a.bounces = a.bounces if a.bounces is not None else (4 if lattice else 5)
+    a.filter = a.filter if a.filter is not None else (0 if lattice else 5)
+    max_follows = (1 << 30) if lattice else 1000
     W, H = (int(v) for v in a.size.lower().split("x"))
 
     import torch
@@ -98,11 +110,15 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=device)
 
-    wl = workloads.Workload(a.scene, W, H)
+    if lattice:
+        nx, ny, nz = (int(v) for v in a.lattice.lower().split("x"))
+        wl = workloads.LatticeWorkload(W, H, nx, ny, nz)
+    else:
+        wl = workloads.Workload(a.scene, W, H)
     ctx = hiplib.Context(local_rank)
     ctx.upload_scene(wl.buffers)
     ctx.resize(W, H)
-    backend = parallel.HipBackend(ctx, wl, a.spp, a.bounces, a.filter, device)
+    backend = parallel.HipBackend(ctx, wl, a.spp, a.bounces, a.filter, device, max_follows=max_follows)
     frame = parallel.TiledFrame(backend, W, H, rank, world,
                                 hiplib.IMAGE_FILTERED if a.filter else hiplib.IMAGE_COLOR)
 
@@ -189,7 +205,13 @@ def main():
     avg_launch_ms = tm.ms[didx] / max(launches, 1)
     primary_rays = float(cnt.paths)
     sec_visits, sec_tests = cnt.node_visits - cnt.primary_node_visits, cnt.tri_tests - cnt.primary_tri_tests
-    if dominant == "wf_extend":    # every non-primary traversal; reads a 32 B ray, writes a 16 B hit per ray
+    if dominant == "wf_extend" and lattice:
+        # scenes beyond the L2s: the primary rays that enter the scene box are walked by the extend kernel too
+        # (stage 0), so all visits and tests are its work (a ray that misses the box costs the primary kernel one visit)
+        alg_bytes = 48.0 * (cnt.node_visits + cnt.tri_tests) + 48.0 * cnt.rays
+        ops = 25.0 * cnt.node_visits + 51.0 * cnt.tri_tests
+        kname = "rt_wf_extend_kernel"
+    elif dominant == "wf_extend":  # every non-primary traversal; reads a 32 B ray, writes a 16 B hit per ray
         alg_bytes = 48.0 * (sec_visits + sec_tests) + 48.0 * (cnt.rays - primary_rays)
         ops = 25.0 * sec_visits + 51.0 * sec_tests
         kname = "rt_wf_extend_kernel"
@@ -214,19 +236,22 @@ def main():
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get(f"{a.scene}_{W}x{H}_{kname}_bytes_per_launch")
+                traffic = json.load(f).get(f"{wl.name if lattice else a.scene}_{W}x{H}_{kname}_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
         "metric": "Mrays/s (trace+filter), scene.obj 1080p 4spp" if (a.scene, W, H, a.spp) == ("scene", 1920, 1080, 4)
-                  else f"Mrays/s (trace+filter), {a.scene} {W}x{H} {a.spp}spp",
+                  else f"Mrays/s (trace+filter), {wl.name if lattice else a.scene} {W}x{H} {a.spp}spp",
         "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         **({"rehearsal": "gloo collectives, all ranks on GPU 0: not a measurement"} if rehearsal else {}),
-        "config": {"workload": f"{a.scene}.obj {W}x{H} {a.spp}spp maxBounces {a.bounces} + {a.filter}-iteration "
-                               f"a-trous filter, SURVEY 8(d) auto camera + harness quad light"
-                               f" (BASELINE.json configs[2])",
+        "config": {"workload": (f"{wl.info.num_triangles} triangles: suzanne.obj on a jittered {a.lattice} lattice (PCG32 seed "
+                                f"0x5EED), {W}x{H} {a.spp}spp maxBounces {a.bounces}, {a.filter} filter iterations, "
+                                f"MAX_FOLLOWS lifted (BASELINE.json configs[4], SURVEY 8(d) config #5)") if lattice else
+                               (f"{a.scene}.obj {W}x{H} {a.spp}spp maxBounces {a.bounces} + {a.filter}-iteration "
+                                f"a-trous filter, SURVEY 8(d) auto camera + harness quad light"
+                                f" (BASELINE.json configs[2])"),
                    "triangles": wl.info.num_triangles, "nodes": wl.info.num_nodes, "emitters": wl.num_emitters,
                    "schedule": "wavefront pipeline, samples of a frame traced concurrently (rt_trace_batch)",
                    "parallelism": f"{world} x screen-space row strips, halo {backend.halo} rows, gather to rank 0"},
@@ -239,9 +264,11 @@ def main():
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 4), "launches": launches,
                      "algorithmic_bytes_per_launch": round(alg_bytes_per_launch),
-                     "note": "scene + BVH (<1 MB) stay resident in every XCD's L2, so these algorithmic bytes are "
-                             "served by L1/L2 and not by HBM (traffic = measured HBM bytes); the kernel is limited by "
-                             "vector-L1 gather throughput, fp32 VALU issue and divergence (see valu)",
+                     "note": ("scene + BVH are beyond every cache: the algorithmic bytes are HBM bytes (traffic = measured "
+                              "HBM bytes per launch)") if lattice else
+                             ("scene + BVH (<1 MB) stay resident in every XCD's L2, so these algorithmic bytes are "
+                              "served by L1/L2 and not by HBM (traffic = measured HBM bytes); the kernel is limited by "
+                              "vector-L1 gather throughput, fp32 VALU issue and divergence (see valu)"),
                      "valu": {"achieved_Tops": round(tops, 4), "peak_Tops_no_fma": VALU_PEAK_TOPS_NOFMA,
                               "frac": round(tops / VALU_PEAK_TOPS_NOFMA, 4),
                               "ops_model": "25 per node visit + 51 per triangle test (SURVEY 8(d))"}},
@@ -252,7 +279,7 @@ def main():
                                  "to exact-distance ties, fewer rays traced; not part of `value`"}
     if world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(wl, a.spp, a.bounces, a.filter)
+            out["cpu_baseline"] = cpu_baseline(wl, a.spp, a.bounces, a.filter, max_follows)
         except Exception as e:  # the checker library is test infrastructure; never fatal for the measurement
             out["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port",
                                    "sample": f"unavailable: {e}"}
