@@ -102,14 +102,21 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
             const int e = ((oy + 1) * 4 + ly) * cols + step + lx + ox * step;
             const float4 ctmp = sCol[e];
             if (ctmp.x != ctmp.x || ctmp.y != ctmp.y || ctmp.z != ctmp.z || ctmp.w != ctmp.w) continue;
-            float4 t = sub4(cval, ctmp);
-            const float c_w = fminf(expf(divUniform(-dot4(t, t), c_phi, r_c)), 1.0f);
-            t = sub4(nval, unpackSnorm4(sNrm[e]));
-            const float dist2 = fmaxf(divUniform(dot4(t, t), stepsq, r_s), 0.0f);
-            const float n_w = fminf(expf(divUniform(-dist2, n_phi, r_n)), 1.0f);
-            t = sub4(pval, unpackHalf4(sPos[e]));
-            const float p_w = fminf(expf(divUniform(-dot4(t, t), p_phi, r_p)), 1.0f);
-            const float weight = c_w * n_w * p_w;
+            float weight = 1.0f; // the centre tap: all three distances are 0 (or NaN, which the min below drops): weight 1
+            if (ox != 0 || oy != 0) {
+                float4 t = sub4(cval, ctmp);
+                // c_w * n_w * p_w = min(exp(a),1) * min(exp(b),1) * min(exp(c),1) with a, b, c <= 0 (or NaN, for which
+                // the oracle's min returns 1): formed as ONE exp(a + b + c) with NaN arguments replaced by 0.  Same value up
+                // to the rounding of two products (about 1e-7 relative; the result is stored as fp16), a third of the
+                // transcendental work.
+                const float a = fminf(divUniform(-dot4(t, t), c_phi, r_c), 0.0f);
+                t = sub4(nval, unpackSnorm4(sNrm[e]));
+                const float dist2 = fmaxf(divUniform(dot4(t, t), stepsq, r_s), 0.0f);
+                const float b = fminf(divUniform(-dist2, n_phi, r_n), 0.0f);
+                t = sub4(pval, unpackHalf4(sPos[e]));
+                const float c = fminf(divUniform(-dot4(t, t), p_phi, r_p), 0.0f);
+                weight = expf((a + b) + c);
+            }
             const float k = kern[2 - (ox != 0) - (oy != 0)];
             sum.x += ctmp.x * weight * k;
             sum.y += ctmp.y * weight * k;
