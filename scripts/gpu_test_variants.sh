@@ -1,0 +1,11 @@
+#!/bin/bash
+# The GPU parity suite under scheduling settings other than the defaults: the picture, the ids and the counters must not
+# depend on them.  (1) what the launcher chooses for scenes beyond the L2s, forced onto the small test scenes;
+# (2) early end of the walk phase for full waves, single-ray waves allowed, early refill.
+set -eu
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}"
+mkdir -p gpurun_out
+RT_WF_WALK_STOP=3 RT_WF_WALK_MIN=1 RT_WF_REFILL=32 RT_WF_COOP=1 RT_WF_PRIMARY_VIA_EXTEND=1 \
+  timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread | tail -2
+RT_WF_WALK_STOP=1 RT_WF_WALK_MIN=40 RT_WF_MIN_RAYS=1 RT_WF_REFILL=8 \
+  timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread | tail -2
