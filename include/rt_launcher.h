@@ -86,7 +86,13 @@ enum rt_flags {
      * first: a ray that misses it is never cast, the others stop at the first hit nearer than the light
      * (any-hit, reference SURVEY 8(f) rank 4).  Same answer except when another triangle is hit at exactly the
      * light's distance; the ray / visit / test counters then count the work actually done. */
-    RT_FLAG_FAST_SHADOWS = 16
+    RT_FLAG_FAST_SHADOWS = 16,
+    /* NOT the reference's arithmetic; off by default.  Ray-triangle tests (reference geometry.glsl:31-51, one-sided
+     * Moeller-Trumbore) are replaced by the watertight test of Woop, Benthin and Wald (JCGT 2013), still one-sided:
+     * a ray through an edge or vertex shared by two triangles cannot slip between them.  Hit distances and
+     * barycentrics differ from the reference's in the last bits, primary-hit ids only at such edges.  RT_KERNEL_TRACE3
+     * only; not together with RT_FLAG_FAST_SHADOWS. */
+    RT_FLAG_WATERTIGHT = 32
 };
 
 typedef struct rt_rect {

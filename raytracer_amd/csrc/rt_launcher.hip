@@ -588,6 +588,8 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         const int xcdRemap = hot > (size_t)3 * 1024 * 1024;
         const size_t tilePixels = (size_t)(r.x1 - r.x0) * (size_t)(r.y1 - r.y0);
         if (tilePixels == 0) return RT_OK;
+        if ((p->flags & RT_FLAG_WATERTIGHT) && (p->flags & RT_FLAG_FAST_SHADOWS))
+            return fail(c, RT_EINVAL, "rt_trace: RT_FLAG_WATERTIGHT and RT_FLAG_FAST_SHADOWS cannot be combined");
         const bool perPixel = (p->flags & RT_FLAG_PER_PIXEL_KERNEL) || p->maxBounces > 30 ||
                               tilePixels * (size_t)n > ((size_t)1 << 30);
         if (perPixel) {

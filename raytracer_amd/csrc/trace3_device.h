@@ -218,6 +218,71 @@ __device__ __forceinline__ void testLeaf(const float4 *__restrict__ tris48, int 
     }
 }
 
+// ---------------------------------------------------------------- watertight variant (opt-in)
+// RT_FLAG_WATERTIGHT: the ray-triangle test of Woop, Benthin and Wald ("Watertight Ray/Triangle Intersection",
+// JCGT 2013) in place of the reference's Möller-Trumbore.  NOT the reference's arithmetic (a ray through a shared edge or
+// vertex can slip between two triangles there; here it cannot): the triangle is translated to the ray origin and
+// sheared so that the ray runs along +z, the three edge functions U, V, W are 2-D cross products of the ORIGINAL
+// vertices (read from the 128-byte records; v0 + e1 would not reproduce v1 bit for bit), and an edge function that
+// comes out as exactly 0 is recomputed in double precision, so two triangles that share an edge always agree on
+// which side of it the ray passes.  One-sided like the reference (back faces are culled, geometry.glsl:38), same
+// strict `<` on t, same (u, v) = weights of v1 and v2.
+struct WtRay {
+    int kx, ky, kz;
+    float Sx, Sy, Sz;
+};
+__device__ __forceinline__ float comp3(f3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+__device__ __forceinline__ WtRay wtSetup(f3 d) {
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    WtRay r;
+    r.kz = ax > ay ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+    r.kx = r.kz == 2 ? 0 : r.kz + 1;
+    r.ky = r.kx == 2 ? 0 : r.kx + 1;
+    const float dz = comp3(d, r.kz);
+    if (dz < 0.0f) { // keep the winding
+        const int t = r.kx;
+        r.kx = r.ky;
+        r.ky = t;
+    }
+    r.Sx = comp3(d, r.kx) / dz;
+    r.Sy = comp3(d, r.ky) / dz;
+    r.Sz = 1.0f / dz;
+    return r;
+}
+__device__ __forceinline__ void testTriangleWt(f3 v0, f3 v1, f3 v2, int i, f3 origin, const WtRay &r, float &nearest,
+                                               int &hitTri, float &hitT, float &hitU, float &hitV) {
+    const f3 A = v0 - origin, B = v1 - origin, C = v2 - origin;
+    const float Az = comp3(A, r.kz), Bz = comp3(B, r.kz), Cz = comp3(C, r.kz);
+    const float Ax = comp3(A, r.kx) - r.Sx * Az, Ay = comp3(A, r.ky) - r.Sy * Az;
+    const float Bx = comp3(B, r.kx) - r.Sx * Bz, By = comp3(B, r.ky) - r.Sy * Bz;
+    const float Cx = comp3(C, r.kx) - r.Sx * Cz, Cy = comp3(C, r.ky) - r.Sy * Cz;
+    float U = Cx * By - Cy * Bx, V = Ax * Cy - Ay * Cx, W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) { // on (or within rounding of) an edge: decide in double precision
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        V = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    if (U < 0.0f || V < 0.0f || W < 0.0f) return; // outside, or a back face
+    const float det = (U + V) + W;
+    if (!(det > 0.0f)) return;
+    const float T = (U * (r.Sz * Az) + V * (r.Sz * Bz)) + W * (r.Sz * Cz);
+    const float invDet = 1.0f / det;
+    const float t = T * invDet;
+    if (t >= 0.0f && t < nearest) {
+        nearest = t;
+        hitT = t;
+        hitU = V * invDet;
+        hitV = W * invDet;
+        hitTri = i;
+    }
+}
+__device__ __forceinline__ void testLeafWt(const RtTri128 *__restrict__ tris, int first, int end, f3 origin, f3 dir,
+                                           float &nearest, int &hitTri, float &hitT, float &hitU, float &hitV) {
+    const WtRay r = wtSetup(dir);
+    for (int i = first; i < end; ++i)
+        testTriangleWt(ld3(tris[i].v0), ld3(tris[i].v1), ld3(tris[i].v2), i, origin, r, nearest, hitTri, hitT, hitU, hitV);
+}
+
 // ---------------------------------------------------------------- node fetch
 // LDS copy of the first sc.cacheNodes box records (32 bytes per node; only used with the packed node form).
 // An LDS read costs ~64 cycles against several hundred for an L2 hit, and the node walk is one long chain
@@ -286,7 +351,7 @@ __device__ __forceinline__ void loadNodeT(const RtScene &sc, int node, float4 &b
 // ---------------------------------------------------------------- traversal
 // intersectGeometry's loop (trace3.cs:226-269) + intersectTriangles (:172-186).
 // Returns false when the MAX_FOLLOWS abort was taken (trace3.cs:228-234).
-template <int NODES = NODES_ANY>
+template <int NODES = NODES_ANY, bool WATERTIGHT = false>
 __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origin, f3 dir, f3 invdir, Hit &hit) {
     // "while-while" form: every lane first walks nodes until it holds a leaf whose box it entered
     // (or runs out of nodes), then the wave tests leaf triangles together.  Per lane the sequence of
@@ -330,7 +395,10 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
             }
         }
         if (leafCount <= 0) break;
-        testLeaf<true>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
+        if (WATERTIGHT)
+            testLeafWt(sc.tris128, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
+        else
+            testLeaf<true>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
         tests += (unsigned)leafCount;
     }
     c.lastIterations = iterations;
@@ -350,10 +418,11 @@ __device__ __forceinline__ RtMtl fetchMtl(const RtScene &sc, int i) {
 }
 
 // intersectGeometry's epilogue (trace3.cs:259-276): attributes of the closest hit
+template <bool WATERTIGHT = false>
 __device__ __forceinline__ void intersectGeometry(const RtScene &sc, PathCtx &c, f3 origin, f3 dir, f3 invdir,
                                                   Surface &SI) {
     Hit h;
-    traverse(sc, c, origin, dir, invdir, h);
+    traverse<NODES_ANY, WATERTIGHT>(sc, c, origin, dir, invdir, h);
     SI.tridx = h.tridx;
     SI.normal = F3(0, 0, 0);
     SI.point = F3(0, 0, 0);
@@ -398,9 +467,10 @@ __device__ __forceinline__ bool sameTriangle(const RtScene &sc, int tridx, const
 }
 
 // visible(), trace3.cs:487-497
+template <bool WATERTIGHT = false>
 __device__ __forceinline__ bool visible(const RtScene &sc, PathCtx &c, f3 origin, f3 wi, const LightTri &t) {
     Hit h;
-    traverse(sc, c, origin, wi, rcp3(wi), h);
+    traverse<NODES_ANY, WATERTIGHT>(sc, c, origin, wi, rcp3(wi), h);
     return sameTriangle(sc, h.tridx, t);
 }
 

@@ -20,6 +20,7 @@
 //    reductions and issued as one atomic per wave and counter.
 #include "trace3_device.h"
 
+template <bool WATERTIGHT>
 __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img, rt_trace_params p, rt_rect tile,
                                                         int tilesX, int tilesY, int xcdRemap,
                                                         RtCountersDev *counters) {
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
         const size_t pix = (size_t)y * W + x;
         for (int bounces = 0;; ++bounces) {
             Surface SI;
-            intersectGeometry(sc, c, origin, dir, invdir, SI);
+            intersectGeometry<WATERTIGHT>(sc, c, origin, dir, invdir, SI);
             const bool found = SI.tridx != -1;
             RtMtl m = fetchMtl(sc, SI.matidx);
             if (found) {
@@ -95,8 +96,8 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
             const LightTri light = loadLight(sc, li);
             DirectTerms T;
             estimateDirectPrepare(c, origin, dir, SI.normal, m, bounces, light, T);
-            const bool vis1 = visible(sc, c, origin, T.wi1, light);
-            const bool vis2 = visible(sc, c, origin, T.wi2, light);
+            const bool vis1 = visible<WATERTIGHT>(sc, c, origin, T.wi1, light);
+            const bool vis2 = visible<WATERTIGHT>(sc, c, origin, T.wi2, light);
             const f3 Ke30 = ld3(fetchMtl(sc, light.mtlIndex).Ke) * 30.0f;
             const f3 Ld = estimateDirectResolve(T.f1, T.w1, T.lp1, T.cond1, T.f2, T.w2, T.bp2, T.cond2, Ke30, vis1, vis2) /
                           light_prob;
@@ -140,7 +141,7 @@ hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace
     const int tilesX = (tw + 15) / 16, tilesY = (th + 15) / 16;
     const int ntiles = tilesX * tilesY;
     const int nblocks = ((ntiles + 7) / 8) * 8; // multiple of 8 so that the XCD re-map is a bijection
-    hipLaunchKernelGGL(rt_trace3_kernel, dim3(nblocks), dim3(256), 0, stream, sc, img, p, tile, tilesX, tilesY,
-                       xcdRemap, counters);
+    auto kernel = (p.flags & RT_FLAG_WATERTIGHT) ? rt_trace3_kernel<true> : rt_trace3_kernel<false>;
+    hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(256), 0, stream, sc, img, p, tile, tilesX, tilesY, xcdRemap, counters);
     return hipGetLastError();
 }

@@ -94,7 +94,7 @@ __device__ __forceinline__ void flushCounters(const WfParams &p, RtCountersDev *
 } // namespace
 
 // ------------------------------------------------------------------------------------------ primary
-template <int NODES>
+template <int NODES, bool WATERTIGHT>
 __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
                                                             rt_rect tile, int tilesX, int tilesY, int xcdRemap,
                                                             int logicalBlocks, RtCountersDev *counters) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages
             c.rays = 1;
             c.visits = 1;
         } else if (!defer) { // (the LDS copy of the nodes exists: a lane of this block enters the scene)
-            traverse<NODES>(sc, c, ld3(p.eye), dir, invdir, h);
+            traverse<NODES, WATERTIGHT>(sc, c, ld3(p.eye), dir, invdir, h);
         }
         const size_t pix = (size_t)y * W + x;
         if ((p.flags & RT_FLAG_AUX) && !defer) {
@@ -419,7 +419,7 @@ struct WaveShare { // phase-2 exchange area of one wave (3 KB); first/ro/rd/key 
     unsigned long long key[64];   // closest accepted hit so far: (bits(t), triangle)
 };
 
-template <int NODES>
+template <int NODES, bool WATERTIGHT>
 __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams p, WfBuffers wf, int stage,
                                                            int refillLanes, RtCountersDev *counters) {
     const int n = min(wf.counts[stage], wf.capacity);
@@ -621,12 +621,15 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 unsigned long long heads = ws->heads[0];
                 int g = lane, o = 0, tri = 0;
                 float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
+                // (RT_FLAG_WATERTIGHT: a0..a2 are the three vertices from the 128-byte records instead of {v0, e1, e2})
+                const float4 *triData = WATERTIGHT ? reinterpret_cast<const float4 *>(sc.tris128) : sc.tris48;
+                constexpr int triStride = WATERTIGHT ? 8 : 3;
                 if (g < totalTests) {
                     o = rankBase + __popcll(heads & atOrBelow);
                     tri = ws->first[o] + g;
-                    a0 = sc.tris48[3 * tri];
-                    a1 = sc.tris48[3 * tri + 1];
-                    a2 = sc.tris48[3 * tri + 2];
+                    a0 = triData[triStride * tri];
+                    a1 = triData[triStride * tri + 1];
+                    a2 = triData[triStride * tri + 2];
                 }
                 for (int base = 0; base < totalTests; base += 64) {
                     const int gn = g + 64;
@@ -637,15 +640,19 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                     if (gn < totalTests) {
                         on = rankBase + __popcll(heads & atOrBelow);
                         trin = ws->first[on] + gn;
-                        n0 = sc.tris48[3 * trin];
-                        n1 = sc.tris48[3 * trin + 1];
-                        n2 = sc.tris48[3 * trin + 2];
+                        n0 = triData[triStride * trin];
+                        n1 = triData[triStride * trin + 1];
+                        n2 = triData[triStride * trin + 2];
                     }
                     if (g < totalTests) {
                         const float4 ro = ws->ro[o], rd = ws->rd[o];
                         float tn = ro.w, tt = 0.0f, tu = 0.0f, tv = 0.0f;
                         int th = -1;
-                        testTriangle<false>(a0, a1, a2, tri, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), tn, th, tt, tu, tv);
+                        if (WATERTIGHT)
+                            testTriangleWt(xyz(a0), xyz(a1), xyz(a2), tri, F3(ro.x, ro.y, ro.z), wtSetup(F3(rd.x, rd.y, rd.z)), tn,
+                                           th, tt, tu, tv);
+                        else
+                            testTriangle<false>(a0, a1, a2, tri, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), tn, th, tt, tu, tv);
                         if (th >= 0) { // t >= 0 and t < the ray's nearest; -0.0 is keyed as +0.0
                             const unsigned long long key =
                                 ((unsigned long long)__float_as_uint(tt + 0.0f) << 32) | (unsigned)tri;
@@ -664,8 +671,12 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                     const unsigned long long key = ws->key[rank];
                     if (key != ~0ull) { // the owner repeats the winning test: same arithmetic, same t, u, v
                         const int wtri = (int)(unsigned)(key & 0xFFFFFFFFull);
-                        testTriangle<false>(sc.tris48[3 * wtri], sc.tris48[3 * wtri + 1], sc.tris48[3 * wtri + 2], wtri, origin,
-                                            dir, nearest, hitTri, hitT, hitU, hitV);
+                        if (WATERTIGHT)
+                            testTriangleWt(xyz(triData[8 * wtri]), xyz(triData[8 * wtri + 1]), xyz(triData[8 * wtri + 2]), wtri,
+                                           origin, wtSetup(dir), nearest, hitTri, hitT, hitU, hitV);
+                        else
+                            testTriangle<false>(sc.tris48[3 * wtri], sc.tris48[3 * wtri + 1], sc.tris48[3 * wtri + 2], wtri,
+                                                origin, dir, nearest, hitTri, hitT, hitU, hitV);
                     }
                     tests += (unsigned)cnt;
                 }
@@ -676,7 +687,10 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         WT(const long long c5 = clock64();)
         if (active && leafCount > 0) {
             if (!shared) { // every lane tests its own leaf, four triangles per batch of loads
-                testLeaf<false>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+                if (WATERTIGHT)
+                    testLeafWt(sc.tris128, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+                else
+                    testLeaf<false>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
                 tests += (unsigned)leafCount;
             }
             if (bounded && hitTri >= 0) next = -1; // any hit nearer than the light settles a shadow ray
@@ -758,18 +772,24 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     scExtend.cacheNodes = sc.packedLeaves ? std::max(0, std::min(sc.numNodes, p.extendCacheNodes)) : 0;
     const size_t extendLds = (size_t)scExtend.cacheNodes * 32 + 4 * sizeof(WaveShare);
     const int primaryBlocks = std::min(nblocks, 256 * p.primaryBlocksPerCU);
-    auto primaryKernel = !sc.packedLeaves ? rt_wf_primary_kernel<NODES_ANY>
-                         : (scPrimary.cacheNodes >= sc.numNodes && sc.numNodes > 0) ? rt_wf_primary_kernel<NODES_PACKED_LDS>
-                                                                                    : rt_wf_primary_kernel<NODES_PACKED>;
+    const bool wt = (p.flags & RT_FLAG_WATERTIGHT) != 0; // opt-in variant of the triangle test (trace3_device.h)
+    const int primaryNodes = !sc.packedLeaves ? NODES_ANY
+                             : (scPrimary.cacheNodes >= sc.numNodes && sc.numNodes > 0) ? NODES_PACKED_LDS : NODES_PACKED;
+    auto primaryKernel = primaryNodes == NODES_ANY ? (wt ? rt_wf_primary_kernel<NODES_ANY, true> : rt_wf_primary_kernel<NODES_ANY, false>)
+                         : primaryNodes == NODES_PACKED_LDS
+                             ? (wt ? rt_wf_primary_kernel<NODES_PACKED_LDS, true> : rt_wf_primary_kernel<NODES_PACKED_LDS, false>)
+                             : (wt ? rt_wf_primary_kernel<NODES_PACKED, true> : rt_wf_primary_kernel<NODES_PACKED, false>);
     hipLaunchKernelGGL(primaryKernel, dim3(primaryBlocks), dim3(256), (size_t)scPrimary.cacheNodes * 32, stream,
                        scPrimary, img, p, wf, tile, tilesX, tilesY, xcdRemap, nblocks, counters);
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, false);
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
     const int logicBlocks = 256 * 4, extendBlocks = 256 * p.extendBlocksPerCU;
     // the walk's node fetch is chosen here, once per launch (trace3_device.h: loadNodeT)
-    auto extendKernel = !sc.packedLeaves ? rt_wf_extend_kernel<NODES_ANY>
-                        : scExtend.cacheNodes >= sc.numNodes ? rt_wf_extend_kernel<NODES_PACKED_LDS>
-                                                             : rt_wf_extend_kernel<NODES_PACKED>;
+    const int extendNodes = !sc.packedLeaves ? NODES_ANY : scExtend.cacheNodes >= sc.numNodes ? NODES_PACKED_LDS : NODES_PACKED;
+    auto extendKernel = extendNodes == NODES_ANY ? (wt ? rt_wf_extend_kernel<NODES_ANY, true> : rt_wf_extend_kernel<NODES_ANY, false>)
+                        : extendNodes == NODES_PACKED_LDS
+                            ? (wt ? rt_wf_extend_kernel<NODES_PACKED_LDS, true> : rt_wf_extend_kernel<NODES_PACKED_LDS, false>)
+                            : (wt ? rt_wf_extend_kernel<NODES_PACKED, true> : rt_wf_extend_kernel<NODES_PACKED, false>);
     if (p.primaryViaExtend) {
         if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, true);
         hipLaunchKernelGGL(extendKernel, dim3(extendBlocks), dim3(256), extendLds, stream, scExtend, p, wf, 0,
