@@ -24,6 +24,7 @@ int main(int argc, char **argv) {
     float exposure = 1.0f;
     bool autoCamera = false, light = false;
     std::string out = "frame", res = "res", kernel = "trace3";
+    int launchFlags = 0, maxFollows = 1000;
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
@@ -37,6 +38,9 @@ int main(int argc, char **argv) {
         else if (a == "--out") out = next();
         else if (a == "--res") res = next();
         else if (a == "--kernel") kernel = next();
+        else if (a == "--watertight") launchFlags |= RT_FLAG_WATERTIGHT;      // opt-in variants, not the reference's algorithm
+        else if (a == "--fast-shadows") launchFlags |= RT_FLAG_FAST_SHADOWS;
+        else if (a == "--max-follows") maxFollows = std::atoi(next());
         else { std::cerr << "unknown option " << a << std::endl; return -1; }
     }
     try {
@@ -80,6 +84,8 @@ int main(int argc, char **argv) {
         if (kernel == "trace1") tracer.genBlueNoiseBuffers();
         if (kernel == "trace2") tracer.genLtcData();
         tracer.maxBounces = bounces;
+        tracer.launchFlags = launchFlags;
+        tracer.maxFollows = maxFollows;
         filter.iterations = filterIters;
         rtCheck(rtApi().profile(rtCurrentContext(), 1), "rt_profile");
 

@@ -221,7 +221,9 @@ void Tracer::trace(int frameNumber) { // Tracer.cpp:132-198
     compute.setFloat("phongExponent", phongExponent);
     compute.setFloat("specularFactor", specularFactor);
     compute.setFloat("roughness", roughness);
-    const rt_trace_params p = compute.params();
+    rt_trace_params p = compute.params();
+    p.flags = launchFlags;
+    p.maxFollows = maxFollows;
     // image / buffer bindings of Tracer.cpp:165-180 are implicit in the context; the dispatch:
     rtCheck(rtApi().trace(rtCurrentContext(), &p, nullptr), "rt_trace");
 }

@@ -109,6 +109,10 @@ public:
     float timeOverride;
     // uniforms of trace.cs / trace1.cs / trace2.cs whose setters are commented out in Tracer.cpp:147-152
     float phongExponent = 128.0f, specularFactor = 0.2f, roughness = 0.5f;
+    // Not in the reference: launch options of the MI355X launcher (include/rt_launcher.h).  launchFlags: RT_FLAG_*
+    // (e.g. RT_FLAG_WATERTIGHT, RT_FLAG_FAST_SHADOWS: opt-in variants that are not the reference's algorithm);
+    // maxFollows: MAX_FOLLOWS of trace3.cs:214, to be lifted for scenes of millions of triangles.
+    int launchFlags = 0, maxFollows = 1000;
     std::string resourceDir = "res"; // where the sample tables / LUTs are read from
     rt_counters counters();
 };
