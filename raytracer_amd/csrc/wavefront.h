@@ -13,16 +13,16 @@ struct WfSample { // per-sample uniforms of a batch (what differs between succes
 struct WfParams {
     float eye[3], ray00[3], ray01[3], ray10[3], ray11[3];
     int maxBounces, numEmitters, maxFollows, flags, batch;
-    int refillLanes;       // idle lanes of a wave that trigger a refill from the ray queue (64 = only when all are idle)
+    int refillLanes;       // a wave takes new rays when refillLanes/64 of its ray lanes are free (64 = all)
     int primaryViaExtend;   // primary rays that enter the scene box are walked by the extend kernel (stage 0)
     int primaryBlocksPerCU; // the primary kernel's blocks walk over the 16x16 tiles; this many blocks per CU
     int extendBlocksPerCU; // persistent 256-thread blocks per CU of the extend kernel
-    int extendCacheNodes;  // nodes the extend kernel keeps in LDS (40 bytes each, per block)
-    int extendRaysPerWave; // 0 = chosen per launch from the queue size; 8..64 forces it (development knob)
+    int extendCacheNodes;  // nodes the extend kernel keeps in LDS (32 bytes each, per block)
+    int extendRaysPerWave; // 0 = chosen per launch from the queue size; 1..64 forces it (development knob)
     int extendFill;        // rays-per-wave rule: halve while (rays/2) * resident waves * extendFill >= queued rays
     int extendMinRays;     // ... but not below this many rays per wave
-    int walkMin;           // ... if at least walkMin lanes are walking
     int walkStop;          // extend: the node-walk phase of a round ends when walkStop/8 of the walking lanes hold a leaf (8: all)
+    int walkMin;           // ... if at least walkMin lanes are walking
     int extendChunk;       // most queue entries a wave takes with one atomic on the shared cursor
     int extendCoop;        // leaf tests of full waves: 0 lane by lane, 1 cooperative, 2 decided per round (see coopA / coopB)
     int coopA, coopB;      // a round is tested cooperatively when rounds_of_64_pairs * coopA + coopB < 4 * largest_leaf

@@ -13,8 +13,8 @@
 //     logic   one lane per queued path: resolve the two shadow rays of bounce b-1 (MIS direct light),
 //             shade the hit of bounce b (emission, G-buffer at b = 0), stop or emit THREE rays —
 //             light-sample shadow ray, BRDF-sample shadow ray, continuation ray — and re-queue
-//     extend  persistent waves pull 64 rays at a time from the ray queue (one atomic per wave) and
-//             walk the BVH; the three rays of a path are traced concurrently by different lanes
+//     extend  persistent waves pull rays from the ray queue and walk the BVH; the three rays of a path are traced
+//             concurrently by different lanes
 //   blend     per pixel, the samples of the batch are folded into the accumulation image in order
 //
 // so the dependent chain per path is maxBounces+1 traversals instead of 3*maxBounces+1, every wave of
@@ -391,14 +391,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 }
 
 // ------------------------------------------------------------------------------------------ extend
-// Persistent waves.  A wave keeps 64 ray slots; when `refillLanes` of its lanes have finished their ray
-// the idle lanes take the next rays of the stage's queue with ONE atomic for the whole wave.  Measured
-// on MI355X (room.obj 1080p, 116 M secondary rays): refilling only when all 64 lanes are idle (the
-// default, refillLanes = 64) is fastest, 53 ms against 61 ms at 32 or 20 idle lanes and 95 ms at 8 — a
-// wave that takes 64 CONSECUTIVE queue entries gets rays of neighbouring pixels, which read the same
-// nodes and triangles; topping lanes up one by one mixes unrelated rays into the wave, and the loss of
-// coalescing in the vector L1 costs more than the idle lanes did.  Inside, the walk is the same "while-while" as traverse() in trace3_device.h —
-// per ray, node visits and triangle tests happen in the reference's order — kept as resumable state.
+// Persistent waves walk the ray queue of a stage.  Per lane the walk is the "while-while" of traverse() in
+// trace3_device.h kept as resumable state — node visits and triangle tests of a ray happen in the reference's order —
+// and everything else is scheduling, measured on MI355X (DESIGN.md 4.2 has the numbers):
+//   * a wave takes 4..64 rays at a time (few when the queue is short, so that every resident wave has work), its first
+//     chunk by position, later ones from a shared cursor;
+//   * new rays are taken when all ray lanes are free — 64 CONSECUTIVE queue entries are rays of neighbouring pixels,
+//     which read the same nodes and triangles, and topping lanes up one by one costs more in the vector L1 than the
+//     idle lanes did (room.obj: 53 ms against 61 ms at 32 idle lanes) — or, for scenes beyond the L2s, where there is
+//     no such locality, when half of them are (`refillLanes`);
+//   * a round = phase 1, lanes walk nodes until they hold a leaf (optionally only until a share of them do,
+//     `walkStop`), then phase 2, the leaves' triangles are tested, lane by lane or shared out over the wave.
 
 #ifdef RT_WAVE_TRACE
 // Development aid (make hip EXTRA_HIPFLAGS=-DRT_WAVE_TRACE, scripts/wave_trace.py): per-wave timeline of the extend kernel.
