@@ -5,7 +5,7 @@ Metric: Mrays/s (+ ms/frame) of trace + filter on scene.obj, 1920x1080, 4 spp, m
 5 à-trous iterations (BASELINE.json configs[2]), on N GPUs of one node.
 A "step" is one frame: 4 trace dispatches (sample k: time 1.25+0.0625k, blendFactor k/(k+1)),
 5 filter passes, and for N > 1 the gather of the finished strips to rank 0 (strong scaling: the
-frame is fixed, each rank owns a strip of rows plus the filter halo).  All inputs are resident in
+frame is fixed, each rank owns a screen-space tile plus the filter halo).  All inputs are resident in
 HBM before the timed region.  A ray = one closest-hit BVH traversal (primary, continuation or
 shadow), counted by the device counters the parity tests check.
 
@@ -146,16 +146,21 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
 
+    frame_sha = None
+    if os.environ.get("RT_BENCH_CHECKSUM") and rank == 0:  # rehearsal aid: every N must assemble the same picture
+        import hashlib
+        img = ctx.readback(hiplib.IMAGE_FILTERED if a.filter else hiplib.IMAGE_COLOR)
+        frame_sha = hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest()
     cnt = ctx.counters()
     tm = ctx.timings()
-    # Strips overlap by the filter halo, so the rays the ranks traced add up to more than the frame has.  `value`
-    # counts the frame's own rays: every rank traces its strip once more WITHOUT the halo (outside the timed region;
-    # a pixel's rays do not depend on the tile it is traced in) and the strips partition the frame.
+    # Tiles overlap by the filter halo, so the rays the ranks traced add up to more than the frame has.  `value`
+    # counts the frame's own rays: every rank traces its tile once more WITHOUT the halo (outside the timed region;
+    # a pixel's rays do not depend on the tile it is traced in) and the tiles partition the frame.
     frame_rays = float(cnt.rays) / max(a.steps, 1)
     if world > 1:
         ctx.profile(False)
         ctx.reset_counters()
-        backend.trace(frame.strip, 0)
+        backend.trace(frame.tile, 0)
         ctx.sync()
         frame_rays = float(ctx.counters().rays)
     # Opt-in extra, outside the measured value: the same frames with RT_FLAG_FAST_SHADOWS (not the reference's
@@ -254,7 +259,8 @@ def main():
                                 f" (BASELINE.json configs[2])"),
                    "triangles": wl.info.num_triangles, "nodes": wl.info.num_nodes, "emitters": wl.num_emitters,
                    "schedule": "wavefront pipeline, samples of a frame traced concurrently (rt_trace_batch)",
-                   "parallelism": f"{world} x screen-space row strips, halo {backend.halo} rows, gather to rank 0"},
+                   "parallelism": f"{world} ranks as a {frame.grid[0]} x {frame.grid[1]} grid of screen-space tiles, halo "
+                                  f"{backend.halo} px, one gather to rank 0"},
         "rays_per_frame": frame_rays, "rays_traced_per_frame_incl_halo": rays / a.steps,
         "node_visits_per_frame": visits / a.steps,
         "tri_tests_per_frame": tests / a.steps,
@@ -273,6 +279,8 @@ def main():
                               "frac": round(tops / VALU_PEAK_TOPS_NOFMA, 4),
                               "ops_model": "25 per node visit + 51 per triangle test (SURVEY 8(d))"}},
     }
+    if frame_sha is not None:
+        out["frame_sha256"] = frame_sha
     if fast_ms is not None:
         out["opt_in"] = {"fast_shadows_ms_per_frame": round(fast_ms, 4),
                          "note": "RT_FLAG_FAST_SHADOWS: light-first any-hit shadow rays (SURVEY 8(f) rank 4); same image up "

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Rehearsal of bench.py's N > 1 path on a ONE-GPU box: N ranks share GPU 0, collectives over gloo through host
-# memory (RT_BENCH_COLLECTIVES=gloo).  Checks the code path and the bookkeeping (strips, halo, gather, frame-ray
-# count), NOT performance.   usage: scripts/rehearse_multi_gpu.sh [ranks=2]
+# memory (RT_BENCH_COLLECTIVES=gloo).  Checks the code path and the bookkeeping (tiles, halo, gather: the assembled frame
+# must be the one-rank frame bit for bit; frame-ray count), NOT performance.   usage: scripts/rehearse_multi_gpu.sh [ranks=2]
 set -eu
 N=${1:-2}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$REPO"
-export RT_BENCH_COLLECTIVES=gloo MASTER_ADDR=127.0.0.1
+export RT_BENCH_COLLECTIVES=gloo RT_BENCH_CHECKSUM=1 MASTER_ADDR=127.0.0.1
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/rehearse_1.json
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus "$N" --steps 3 --warmup 1 > gpurun_out/rehearse_$N.json
@@ -19,5 +19,7 @@ print("1 rank :", a["rays_per_frame"], a["ms_per_frame"])
 print(f"{n} ranks:", b["rays_per_frame"], b["ms_per_frame"], "incl. halo", b["rays_traced_per_frame_incl_halo"], b["n_gpus"])
 assert b["n_gpus"] == int(n) and b["rays_per_frame"] == a["rays_per_frame"], "the strips' rays must add up to the frame's"
 assert b["rays_traced_per_frame_incl_halo"] >= b["rays_per_frame"]
+assert b["frame_sha256"] == a["frame_sha256"], "the assembled frame differs from the one-rank frame"
+print("assembled frame identical:", b["frame_sha256"][:16])
 print("ok")
 PY

@@ -352,10 +352,10 @@ def test_leaf_of_more_than_32_triangles_takes_the_general_node_path(ctx):
         assert np.array_equal(got[k].view(np.uint8), pp[k].view(np.uint8)), k
 
 
-def test_config4_size_eight_strips_equal_the_full_frame(ctx):
+def test_config4_size_eight_tiles_equal_the_full_frame(ctx):
     """BASELINE.json configs[3] at its full size (scene.obj 3840x2160, 16 spp, 5 filter passes) through the property
-    the 8-GPU decomposition rests on: each of the eight strips, traced with its halo and filtered on its own,
-    reproduces the rows of the frame rendered in one piece, bit for bit."""
+    the 8-GPU decomposition rests on: each of the eight tiles (the 4 x 2 grid raytracer_amd/parallel.py picks), traced
+    with its halo and filtered on its own, reproduces its pixels of the frame rendered in one piece, bit for bit."""
     from raytracer_amd import parallel
     W, H, spp, iters, world = 3840, 2160, 16, 5, 8
     wl = workloads.Workload("scene", W, H)
@@ -368,12 +368,13 @@ def test_config4_size_eight_strips_equal_the_full_frame(ctx):
     full_color = ctx.readback(hiplib.IMAGE_COLOR).copy()
     assert np.isfinite(full_color).all() and len(np.unique(full[..., :3])) > 1000
     halo = hiplib.lib().rt_filter_halo(iters)
+    assert parallel.tile_grid(W, H, world, halo) == (4, 2)
     for rank in range(world):
-        y0, y1 = parallel.strip_rows(H, world, rank)
-        traced = parallel.grow_rect((0, y0, W, y1), halo, W, H)
+        x0, y0, x1, y1 = parallel.tile_rect(W, H, world, rank, halo)
+        traced = parallel.grow_rect((x0, y0, x1, y1), halo, W, H)
         ctx.clear()
         ctx.write_image(hiplib.IMAGE_COLOR, np.full((H, W, 4), np.nan, np.float32))   # poison what this rank does not trace
         ctx.trace_samples(wl.rays, wl.eye, rect=traced, **kw)
-        ctx.filter(iters, rect=(0, y0, W, y1))
+        ctx.filter(iters, rect=(x0, y0, x1, y1))
         part = ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16)
-        assert np.array_equal(part[y0:y1], full[y0:y1]), rank
+        assert np.array_equal(part[y0:y1, x0:x1], full[y0:y1, x0:x1]), rank

@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 
 from raytracer_amd import hiplib, parallel, workloads
 
-W, H, SPP, MB, ITERS = 48, 40, 2, 2, 3  # halo 1+3+7 = 11 rows < strip height 20
+W, H, SPP, MB, ITERS = 48, 40, 2, 2, 3  # halo 1+3+7 = 11 px; two ranks split the frame into 24 x 40 tiles
 
 
 class CheckerBackend:
@@ -72,13 +72,29 @@ def _worker(rank, world, port, out_path):
     wl = workloads.Workload("room", W, H)
     b = CheckerBackend(wl, SPP, MB, ITERS)
     frame = parallel.TiledFrame(b, W, H, rank, world, hiplib.IMAGE_FILTERED)
-    assert frame.traced[1] == max(frame.strip[1] - b.halo, 0) and frame.traced[3] == min(frame.strip[3] + b.halo, H)
+    if world == 2:
+        assert frame.grid == (2, 1) and frame.tile == (24 * rank, 0, 24 * rank + 24, H)
+        assert frame.traced == (max(frame.tile[0] - b.halo, 0), 0, min(frame.tile[2] + b.halo, W), H)
+    else:
+        assert frame.grid == (2, 2) and frame.tile == (24 * (rank % 2), 20 * (rank // 2), 24 * (rank % 2) + 24, 20 * (rank // 2) + 20)
     frame.render(0)
     frame.gather(dist)
     if rank == 0:
         np.save(out_path, b.filtered.view(np.uint16))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_tile_grid_partitions_the_frame():
+    for w, h, world, halo, grid in [(1920, 1080, 8, 57, (4, 2)), (1920, 1080, 4, 57, (2, 2)), (1920, 1080, 2, 57, (2, 1)),
+                                    (3840, 2160, 8, 57, (4, 2)), (1920, 1080, 1, 57, (1, 1)), (64, 2000, 4, 11, (1, 4)),
+                                    (1920, 1080, 7, 57, (7, 1)), (1920, 1080, 8, 0, (1, 8))]:
+        assert parallel.tile_grid(w, h, world, halo) == grid, (w, h, world)
+        cover = np.zeros((h, w), np.int32)
+        for r in range(world):
+            x0, y0, x1, y1 = parallel.tile_rect(w, h, world, r, halo)
+            cover[y0:y1, x0:x1] += 1
+        assert (cover == 1).all()
 
 
 def test_strip_partition():
@@ -92,8 +108,8 @@ def test_strip_partition():
 
 
 @pytest.mark.timeout(300)
-def test_two_ranks_equal_one_rank(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])   # a 2 x 1 and a 2 x 2 grid of tiles
+def test_ranks_equal_one_rank(tmp_path, world):
     out = str(tmp_path / "assembled.npy")
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assembled = np.load(out)
