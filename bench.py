@@ -4,8 +4,11 @@
 Metric: Mrays/s (+ ms/frame) of trace + filter on scene.obj, 1920x1080, 4 spp, maxBounces 5,
 5 à-trous iterations (BASELINE.json configs[2]), on N GPUs of one node.
 A "step" is one frame: 4 trace dispatches (sample k: time 1.25+0.0625k, blendFactor k/(k+1)),
-5 filter passes, and for N > 1 the gather of the finished strips to rank 0 (strong scaling: the
-frame is fixed, each rank owns a screen-space tile plus the filter halo).  All inputs are resident in
+5 filter passes, and for N > 1 the gather of the finished tiles to rank 0.  N > 1 is weak scaling by
+default: the path shards by screen-space tiles, every rank owns one 1920x1080 tile (the metric's
+configuration per GPU) of a frame that grows with N — 3840x1080 on 2, 3840x2160 (the resolution of
+BASELINE.json configs[3]) on 4, 7680x2160 on 8 ranks —, traces it with the filter halo, filters it and
+sends it to rank 0.  `--scaling strong` splits the fixed 1920x1080 frame instead.  All inputs are resident in
 HBM before the timed region.  A ray = one closest-hit BVH traversal (primary, continuation or
 shadow), counted by the device counters the parity tests check.
 
@@ -72,6 +75,8 @@ def main():
     ap.add_argument("--bounces", type=int, default=None)
     ap.add_argument("--filter", type=int, default=None)
     ap.add_argument("--lattice", default="37x37x38", help="copies of suzanne.obj for --scene lattice")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = one --size tile per rank (the frame grows with N), strong = --size is the frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     lattice = a.scene == "lattice"
@@ -110,6 +115,12 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=device)
 
+    tileW, tileH = W, H
+    if world > 1 and a.scaling == "weak":
+        # one W x H tile per rank: the frame is the tile grid's columns x rows of them
+        halo = hiplib.lib().rt_filter_halo(a.filter) if a.filter > 0 else 0
+        gx, gy = parallel.tile_grid(W, H, world, halo)
+        W, H = W * gx, H * gy
     if lattice:
         nx, ny, nz = (int(v) for v in a.lattice.lower().split("x"))
         wl = workloads.LatticeWorkload(W, H, nx, ny, nz)
@@ -245,22 +256,25 @@ def main():
         except Exception:
             traffic = None
     out = {
-        "metric": "Mrays/s (trace+filter), scene.obj 1080p 4spp" if (a.scene, W, H, a.spp) == ("scene", 1920, 1080, 4)
+        "metric": "Mrays/s (trace+filter), scene.obj 1080p 4spp" if (a.scene, tileW, tileH, a.spp) == ("scene", 1920, 1080, 4)
                   else f"Mrays/s (trace+filter), {wl.name if lattice else a.scene} {W}x{H} {a.spp}spp",
         "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step, 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         **({"rehearsal": "gloo collectives, all ranks on GPU 0: not a measurement"} if rehearsal else {}),
         "config": {"workload": (f"{wl.info.num_triangles} triangles: suzanne.obj on a jittered {a.lattice} lattice (PCG32 seed "
                                 f"0x5EED), {W}x{H} {a.spp}spp maxBounces {a.bounces}, {a.filter} filter iterations, "
                                 f"MAX_FOLLOWS lifted (BASELINE.json configs[4], SURVEY 8(d) config #5)") if lattice else
                                (f"{a.scene}.obj {W}x{H} {a.spp}spp maxBounces {a.bounces} + {a.filter}-iteration "
                                 f"a-trous filter, SURVEY 8(d) auto camera + harness quad light"
-                                f" (BASELINE.json configs[2])"),
+                                + (f" (BASELINE.json configs[2] = {tileW}x{tileH} per GPU)" if (W, H) != (tileW, tileH)
+                                   else " (BASELINE.json configs[2])")),
                    "triangles": wl.info.num_triangles, "nodes": wl.info.num_nodes, "emitters": wl.num_emitters,
                    "schedule": "wavefront pipeline, samples of a frame traced concurrently (rt_trace_batch)",
-                   "parallelism": f"{world} ranks as a {frame.grid[0]} x {frame.grid[1]} grid of screen-space tiles, halo "
-                                  f"{backend.halo} px, one gather to rank 0"},
+                   "frame": f"{W}x{H}",
+                   "parallelism": f"{world} ranks as a {frame.grid[0]} x {frame.grid[1]} grid of screen-space tiles"
+                                  + (f" of {tileW}x{tileH} (the frame grows with N)" if world > 1 and a.scaling == "weak" else "")
+                                  + f", halo {backend.halo} px, one gather to rank 0"},
         "rays_per_frame": frame_rays, "rays_traced_per_frame_incl_halo": rays / a.steps,
         "node_visits_per_frame": visits / a.steps,
         "tri_tests_per_frame": tests / a.steps,

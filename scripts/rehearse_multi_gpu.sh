@@ -9,7 +9,9 @@ cd "$REPO"
 export RT_BENCH_COLLECTIVES=gloo RT_BENCH_CHECKSUM=1 MASTER_ADDR=127.0.0.1
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/rehearse_1.json
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port 29517 \
-    bench.py --gpus "$N" --steps 3 --warmup 1 > gpurun_out/rehearse_$N.json
+    bench.py --gpus "$N" --steps 3 --warmup 1 --scaling strong > gpurun_out/rehearse_$N.json
+timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port 29518 \
+    bench.py --gpus "$N" --steps 3 --warmup 1 > gpurun_out/rehearse_weak_$N.json
 python - "$N" <<'PY'
 import json, sys
 n = sys.argv[1]
@@ -21,5 +23,8 @@ assert b["n_gpus"] == int(n) and b["rays_per_frame"] == a["rays_per_frame"], "th
 assert b["rays_traced_per_frame_incl_halo"] >= b["rays_per_frame"]
 assert b["frame_sha256"] == a["frame_sha256"], "the assembled frame differs from the one-rank frame"
 print("assembled frame identical:", b["frame_sha256"][:16])
+w = json.loads(open(f"gpurun_out/rehearse_weak_{n}.json").read().strip().splitlines()[-1])
+print(f"{n} ranks, weak:", w["config"]["frame"], w["rays_per_frame"], w["scaling"], w["config"]["parallelism"])
+assert w["scaling"] == "weak" and w["n_gpus"] == int(n) and w["rays_per_frame"] > a["rays_per_frame"]
 print("ok")
 PY
