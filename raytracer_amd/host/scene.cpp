@@ -10,6 +10,9 @@
 #include <iostream>
 #include <random>
 #include <sstream>
+#include <atomic>
+#include <functional>
+#include <thread>
 
 using rtm::vec2;
 using rtm::vec3;
@@ -64,6 +67,41 @@ struct Pending {
     bool isLeft;
     int depth;
 };
+
+// Host threads for the scene-preparation loops (BVH build, lattice replication): $RT_HOST_THREADS, else
+// $OMP_NUM_THREADS (what the GPU boxes set to their CPU share), else the hardware's, at most 16.
+int hostThreads() {
+    for (const char *name : {"RT_HOST_THREADS", "OMP_NUM_THREADS"})
+        if (const char *e = std::getenv(name)) {
+            const int n = std::atoi(e);
+            if (n > 0) return std::min(n, 64);
+        }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hw ? hw : 1u, 16u));
+}
+
+// body(i) for i in [0, n), items handed out in chunks from a shared counter; the results must not depend on which
+// thread runs an item (every use below writes to places that belong to the item alone).
+void parallelFor(size_t n, size_t chunk, const std::function<void(size_t)> &body) {
+    const int threads = (int)std::min<size_t>((size_t)hostThreads(), (n + chunk - 1) / std::max<size_t>(chunk, 1));
+    if (threads <= 1) {
+        for (size_t i = 0; i < n; ++i) body(i);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t b = next.fetch_add(chunk);
+            if (b >= n) return;
+            const size_t e = std::min(n, b + chunk);
+            for (size_t i = b; i < e; ++i) body(i);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+}
 
 GPUTriangle flattenTriangle(const Triangle &t) {
     // reference BVH.cpp:287-297 (and :330-340 for emitters)
@@ -144,70 +182,87 @@ void BVHContainer::build(const std::vector<Triangle> &tris) {
     if (n == 0) return;
 
     std::vector<vec3> cen(n), tmin(n), tmax(n);
-    for (uint32_t i = 0; i < n; ++i) {
+    parallelFor(n, 1 << 16, [&](size_t i) {
         cen[i] = tris[i].centroid();
         tmin[i] = tris[i].min();
         tmax[i] = tris[i].max();
-    }
+    });
     std::vector<uint32_t> idx(n), scratch(n);
     for (uint32_t i = 0; i < n; ++i) idx[i] = i;
 
+    // Level by level: the nodes of a level own disjoint ranges of the index array, so they are processed by
+    // several threads (each node by one thread: the centroid sum of a range must be formed in range order to give
+    // the reference's split plane); numbering the nodes and queueing their children stays sequential, in the order
+    // a first-in-first-out queue would produce (left before right, level after level).
     std::vector<BuildNode> nodes;
-    std::vector<Pending> queue;
-    queue.push_back({0u, n, -1, false, 0});
-    size_t head = 0;
-    while (head < queue.size()) {
-        const Pending p = queue[head++];
-        const int me = (int)nodes.size();
-        nodes.emplace_back();
-        if (p.parent >= 0) {
-            if (p.isLeft) nodes[p.parent].left = me;
-            else nodes[p.parent].right = me;
-        }
+    std::vector<Pending> level{{0u, n, -1, false, 0}}, nextLevel;
+    struct Outcome {
         BuildNode node;
-        node.depth = p.depth;
-        depth = std::max(depth, p.depth);
-        node.lo = node.hi = cen[idx[p.lo]];
-        for (uint32_t k = p.lo; k < p.hi; ++k) {
-            const uint32_t t = idx[k];
-            for (int a = 0; a < 3; ++a) {
-                node.lo[a] = std::min(node.lo[a], tmin[t][a]);
-                node.hi[a] = std::max(node.hi[a], tmax[t][a]);
-            }
-        }
-        const uint32_t count = p.hi - p.lo;
+        uint32_t nl = 0;
         bool split = false;
-        if (count > (uint32_t)MAX_TRIANGLES_IN_NODE) {
-            const vec3 len = node.hi - node.lo;
-            vec3 mean(0.0f);
-            for (uint32_t k = p.lo; k < p.hi; ++k) mean += cen[idx[k]];
-            mean /= (float)count;
-            int axis;
-            if (len.x > len.y && len.x > len.z) axis = 0;
-            else if (len.y > len.z) axis = 1;
-            else axis = 2;
-            uint32_t nl = 0, nr = 0;
+    };
+    std::vector<Outcome> outcome;
+    while (!level.empty()) {
+        outcome.assign(level.size(), Outcome());
+        parallelFor(level.size(), 1, [&](size_t q) {
+            const Pending p = level[q];
+            Outcome &o = outcome[q];
+            BuildNode &node = o.node;
+            node.depth = p.depth;
+            node.lo = node.hi = cen[idx[p.lo]];
             for (uint32_t k = p.lo; k < p.hi; ++k) {
                 const uint32_t t = idx[k];
-                if (cen[t][axis] < mean[axis]) idx[p.lo + nl++] = t; // stable: nl <= k - p.lo
-                else scratch[nr++] = t;
+                for (int a = 0; a < 3; ++a) {
+                    node.lo[a] = std::min(node.lo[a], tmin[t][a]);
+                    node.hi[a] = std::max(node.hi[a], tmax[t][a]);
+                }
             }
-            if (nl > 0 && nr > 0) {
-                std::memcpy(&idx[p.lo + nl], scratch.data(), sizeof(uint32_t) * nr);
-                queue.push_back({p.lo, p.lo + nl, me, true, p.depth + 1});
-                queue.push_back({p.lo + nl, p.hi, me, false, p.depth + 1});
-                split = true;
-            } else if (nl == 0) {
-                std::memcpy(&idx[p.lo], scratch.data(), sizeof(uint32_t) * nr);
+            const uint32_t count = p.hi - p.lo;
+            if (count > (uint32_t)MAX_TRIANGLES_IN_NODE) {
+                const vec3 len = node.hi - node.lo;
+                vec3 mean(0.0f);
+                for (uint32_t k = p.lo; k < p.hi; ++k) mean += cen[idx[k]];
+                mean /= (float)count;
+                int axis;
+                if (len.x > len.y && len.x > len.z) axis = 0;
+                else if (len.y > len.z) axis = 1;
+                else axis = 2;
+                uint32_t nl = 0, nr = 0;
+                uint32_t *right = scratch.data() + p.lo; // this node's own part of the scratch array
+                for (uint32_t k = p.lo; k < p.hi; ++k) {
+                    const uint32_t t = idx[k];
+                    if (cen[t][axis] < mean[axis]) idx[p.lo + nl++] = t; // stable: nl <= k - p.lo
+                    else right[nr++] = t;
+                }
+                if (nl > 0 && nr > 0) {
+                    std::memcpy(&idx[p.lo + nl], right, sizeof(uint32_t) * nr);
+                    o.nl = nl;
+                    o.split = true;
+                } else if (nl == 0) {
+                    std::memcpy(&idx[p.lo], right, sizeof(uint32_t) * nr);
+                }
+            }
+            if (!o.split) {
+                node.first = p.lo;
+                node.count = count;
+            }
+        });
+        nextLevel.clear();
+        for (size_t q = 0; q < level.size(); ++q) {
+            const Pending &p = level[q];
+            const int me = (int)nodes.size();
+            nodes.push_back(outcome[q].node);
+            depth = std::max(depth, p.depth);
+            if (p.parent >= 0) {
+                if (p.isLeft) nodes[p.parent].left = me;
+                else nodes[p.parent].right = me;
+            }
+            if (outcome[q].split) {
+                nextLevel.push_back({p.lo, p.lo + outcome[q].nl, me, true, p.depth + 1});
+                nextLevel.push_back({p.lo + outcome[q].nl, p.hi, me, false, p.depth + 1});
             }
         }
-        if (!split) {
-            node.first = p.lo;
-            node.count = count;
-        }
-        node.left = nodes[me].left;
-        node.right = nodes[me].right;
-        nodes[me] = node;
+        level.swap(nextLevel);
     }
 
     // threaded links (BFS order guarantees parents are visited before children)
@@ -219,11 +274,19 @@ void BVHContainer::build(const std::vector<Triangle> &tris) {
         }
     }
 
+    // leaves emit their triangles in node order: offsets first (sequential), records in parallel
     nodesBuffer.resize(nodes.size());
-    trianglesBuffer.reserve(n);
-    triangleOrder.reserve(n);
+    std::vector<int> firstTri(nodes.size(), 0);
     int triangleIndex = 0;
-    for (size_t i = 0; i < nodes.size(); ++i) {
+    for (size_t i = 0; i < nodes.size(); ++i)
+        if (nodes[i].left < 0) {
+            firstTri[i] = triangleIndex;
+            triangleIndex += (int)nodes[i].count;
+            maxLeafTriangles = std::max(maxLeafTriangles, (int)nodes[i].count);
+        }
+    trianglesBuffer.resize(n);
+    triangleOrder.resize(n);
+    parallelFor(nodes.size(), 4096, [&](size_t i) {
         const BuildNode &b = nodes[i];
         GPUNode g;
         for (int a = 0; a < 3; ++a) {
@@ -238,18 +301,16 @@ void BVHContainer::build(const std::vector<Triangle> &tris) {
             g.numTris = 0;
         } else {
             g.hitNext = skip[i];
-            g.firstTri = triangleIndex;
+            g.firstTri = firstTri[i];
             g.numTris = (int)b.count;
-            triangleIndex += (int)b.count;
-            maxLeafTriangles = std::max(maxLeafTriangles, (int)b.count);
             for (uint32_t k = 0; k < b.count; ++k) {
                 const uint32_t t = idx[b.first + k];
-                triangleOrder.push_back(t);
-                trianglesBuffer.push_back(flattenTriangle(tris[t]));
+                triangleOrder[(size_t)firstTri[i] + k] = t;
+                trianglesBuffer[(size_t)firstTri[i] + k] = flattenTriangle(tris[t]);
             }
         }
         nodesBuffer[i] = g;
-    }
+    });
 }
 
 // ---------------------------------------------------------------------------------------
@@ -462,14 +523,28 @@ void ModelLoader::loadMat(const char *path) {
 }
 
 void ModelLoader::bounds(vec3 &lo, vec3 &hi) const {
+    // min / max are exact whatever the order: blocks of triangles are reduced by several threads, then combined
+    const size_t block = 1 << 16, blocks = (triangles.size() + block - 1) / block;
+    std::vector<vec3> los(blocks, vec3(1e30f)), his(blocks, vec3(-1e30f));
+    parallelFor(blocks, 1, [&](size_t b) {
+        vec3 l(1e30f), h(-1e30f);
+        const size_t end = std::min(triangles.size(), (b + 1) * block);
+        for (size_t i = b * block; i < end; ++i)
+            for (int k = 0; k < 3; ++k)
+                for (int a = 0; a < 3; ++a) {
+                    l[a] = std::min(l[a], triangles[i].vertices[k][a]);
+                    h[a] = std::max(h[a], triangles[i].vertices[k][a]);
+                }
+        los[b] = l;
+        his[b] = h;
+    });
     lo = vec3(1e30f);
     hi = vec3(-1e30f);
-    for (const Triangle &t : triangles)
-        for (int k = 0; k < 3; ++k)
-            for (int a = 0; a < 3; ++a) {
-                lo[a] = std::min(lo[a], t.vertices[k][a]);
-                hi[a] = std::max(hi[a], t.vertices[k][a]);
-            }
+    for (size_t b = 0; b < blocks; ++b)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], los[b][a]);
+            hi[a] = std::max(hi[a], his[b][a]);
+        }
 }
 
 namespace {
@@ -508,12 +583,19 @@ void ModelLoader::replicateLattice(int nx, int ny, int nz, uint64_t seed, float 
     const float pitch = pitchFactor * std::max(ext.x, std::max(ext.y, ext.z));
     triangles.clear();
     emitters.clear();
-    triangles.reserve((size_t)nx * ny * nz * base.size());
+    // the random numbers are drawn in copy order by one generator (cheap); the copies are then written by several threads
+    struct Placement {
+        float R[3][3];
+        vec3 offset;
+    };
+    const size_t copies = (size_t)nx * ny * nz;
+    std::vector<Placement> place(copies);
     Pcg32 rng(seed, 54u);
     const float TWO_PI = 6.28318530717958647692f;
+    size_t c = 0;
     for (int i = 0; i < nx; ++i)
         for (int j = 0; j < ny; ++j)
-            for (int k = 0; k < nz; ++k) {
+            for (int k = 0; k < nz; ++k, ++c) {
                 // uniformly random rotation (Shoemake's quaternion from three uniform numbers)
                 const float u1 = rng.unit(), u2 = rng.unit(), u3 = rng.unit();
                 const float a = std::sqrt(1.0f - u1), b = std::sqrt(u1);
@@ -523,24 +605,35 @@ void ModelLoader::replicateLattice(int nx, int ny, int nz, uint64_t seed, float 
                     {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)},
                     {2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)},
                     {2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)}};
+                std::memcpy(place[c].R, R, sizeof R);
                 const float jx = rng.unit() - 0.5f, jy = rng.unit() - 0.5f, jz = rng.unit() - 0.5f;
                 (void)rng.next(); // seventh draw: reserved (keeps copies on 7-draw boundaries)
-                const vec3 offset(pitch * ((float)i + jitter * jx), pitch * ((float)j + jitter * jy),
-                                  pitch * ((float)k + jitter * jz));
-                auto rot = [&](const vec3 &v) {
-                    return vec3(R[0][0] * v.x + R[0][1] * v.y + R[0][2] * v.z, R[1][0] * v.x + R[1][1] * v.y + R[1][2] * v.z,
-                                R[2][0] * v.x + R[2][1] * v.y + R[2][2] * v.z);
-                };
-                for (const Triangle &t : base) {
-                    Triangle c = t;
-                    for (int v = 0; v < 3; ++v) {
-                        c.vertices[v] = rot(t.vertices[v] - centre) + centre + offset;
-                        c.normals[v] = rot(t.normals[v]);
-                    }
-                    triangles.push_back(c);
-                    if (materialsVector[c.materialIndex]->emitter) emitters.push_back(c);
-                }
+                place[c].offset = vec3(pitch * ((float)i + jitter * jx), pitch * ((float)j + jitter * jy),
+                                       pitch * ((float)k + jitter * jz));
             }
+    triangles.resize(copies * base.size(), base[0]);
+    parallelFor(copies, 64, [&](size_t ci) {
+        const Placement &pl = place[ci];
+        auto rot = [&](const vec3 &v) {
+            return vec3(pl.R[0][0] * v.x + pl.R[0][1] * v.y + pl.R[0][2] * v.z,
+                        pl.R[1][0] * v.x + pl.R[1][1] * v.y + pl.R[1][2] * v.z,
+                        pl.R[2][0] * v.x + pl.R[2][1] * v.y + pl.R[2][2] * v.z);
+        };
+        Triangle *out = triangles.data() + ci * base.size();
+        for (size_t b = 0; b < base.size(); ++b) {
+            Triangle t = base[b];
+            for (int v = 0; v < 3; ++v) {
+                t.vertices[v] = rot(base[b].vertices[v] - centre) + centre + pl.offset;
+                t.normals[v] = rot(base[b].normals[v]);
+            }
+            out[b] = t;
+        }
+    });
+    bool anyEmitter = false;
+    for (const Triangle &t : base) anyEmitter = anyEmitter || materialsVector[t.materialIndex]->emitter;
+    if (anyEmitter)
+        for (const Triangle &t : triangles)
+            if (materialsVector[t.materialIndex]->emitter) emitters.push_back(t);
 }
 
 void ModelLoader::addQuadLight(vec3 c, float hx, float hz, vec3 Ke) {
