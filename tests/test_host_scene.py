@@ -196,3 +196,19 @@ def test_lattice_workload_is_deterministic_and_flat():
     assert np.allclose(n, 1.0, atol=1e-3)
     ext = np.array(a.info.bbox_max[:]) - np.array(a.info.bbox_min[:])
     assert ext[0] > ext[1] * 0.9 and ext[0] > 2.0      # 3 cells along x, 2 along y / z
+
+
+def test_builder_output_does_not_depend_on_the_thread_count(monkeypatch):
+    """The nodes of a level are built by several host threads; the byte streams must be those of one thread
+    (the centroid sum that places a split is formed in range order whatever the thread count)."""
+    import hashlib
+    from raytracer_amd import workloads
+    digests = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("RT_HOST_THREADS", threads)
+        wl = workloads.LatticeWorkload(64, 36, 7, 6, 5)
+        h = hashlib.sha256()
+        for slot in (3, 4, 5, 6):
+            h.update(np.asarray(wl.buffers[slot]).tobytes())
+        digests.append((wl.info.num_nodes, wl.info.depth, h.hexdigest()))
+    assert digests[0] == digests[1] == digests[2]
