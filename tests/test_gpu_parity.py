@@ -378,3 +378,27 @@ def test_config4_size_eight_tiles_equal_the_full_frame(ctx):
         ctx.filter(iters, rect=(x0, y0, x1, y1))
         part = ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16)
         assert np.array_equal(part[y0:y1, x0:x1], full[y0:y1, x0:x1]), rank
+
+
+def test_caller_supplied_stream(ctx):
+    """rt_set_stream: all work of the context is queued on the caller's HIP stream; the picture is the one the
+    context's own stream gives, and NULL switches back.  (The stream is made with the HIP runtime the launcher itself
+    is linked to.)"""
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    wl = workloads.Workload("room", 200, 120)
+    ref = render(ctx, wl, 2, 3)
+    s = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(s)) == 0
+    ctx.set_stream(s.value)
+    try:
+        got = render(ctx, wl, 2, 3)
+        ctx.filter(3)
+        assert hip.hipStreamSynchronize(s) == 0
+        filtered = ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16).copy()
+    finally:
+        ctx.set_stream(0)
+        hip.hipStreamDestroy(s)
+    for k in ALL_IMAGES:
+        assert np.array_equal(got[k].view(np.uint8), ref[k].view(np.uint8)), k
+    ctx.filter(3)
+    assert np.array_equal(ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16), filtered)
