@@ -208,6 +208,10 @@ int rt_tonemap(rt_ctx *ctx, int source_image, float exposure, const rt_rect *til
 int rt_readback(rt_ctx *ctx, int image, void *dst, size_t nbytes);
 int rt_readback_rect_device(rt_ctx *ctx, int image, const rt_rect *tile, void *dst_device, size_t nbytes);
 int rt_write_rect_device(rt_ctx *ctx, int image, const rt_rect *tile, const void *src_device, size_t nbytes);
+/* The same copy, only queued on the context's stream (no counterpart in the reference; for a rank that pastes the tiles
+ * of several peers into its image): `src_device` must stay valid and unchanged until rt_sync or another blocking call
+ * of this context returns. */
+int rt_write_rect_device_async(rt_ctx *ctx, int image, const rt_rect *tile, const void *src_device, size_t nbytes);
 int rt_write_image(rt_ctx *ctx, int image, const void *src_host, size_t nbytes);
 size_t rt_image_pixel_bytes(int image);
 

@@ -863,7 +863,7 @@ int rt_write_image(rt_ctx *c, int image, const void *src, size_t nbytes) {
     return RT_OK;
 }
 
-static int rectCopy(rt_ctx *c, int image, const rt_rect *tile, void *dev, size_t nbytes, bool toCaller) {
+static int rectCopy(rt_ctx *c, int image, const rt_rect *tile, void *dev, size_t nbytes, bool toCaller, bool wait = true) {
     if (!c || !dev) return RT_EINVAL;
     if (image == RT_IMAGE_FILTERED && !toCaller && c->filteredIndex < 0 && c->filt[0].p) c->filteredIndex = 0;
     const ImageRef im = imageOf(c, image);
@@ -879,7 +879,7 @@ static int rectCopy(rt_ctx *c, int image, const rt_rect *tile, void *dev, size_t
     const size_t pitch = (size_t)c->width * im.pixelBytes;
     if (toCaller) HIP_TRY(c, hipMemcpy2DAsync(dev, rowBytes, imgAt, pitch, rowBytes, rows, hipMemcpyDeviceToDevice, c->stream));
     else HIP_TRY(c, hipMemcpy2DAsync(imgAt, pitch, dev, rowBytes, rowBytes, rows, hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (wait) HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
@@ -889,6 +889,10 @@ int rt_readback_rect_device(rt_ctx *c, int image, const rt_rect *tile, void *dst
 
 int rt_write_rect_device(rt_ctx *c, int image, const rt_rect *tile, const void *src_device, size_t nbytes) {
     return rectCopy(c, image, tile, const_cast<void *>(src_device), nbytes, false);
+}
+
+int rt_write_rect_device_async(rt_ctx *c, int image, const rt_rect *tile, const void *src_device, size_t nbytes) {
+    return rectCopy(c, image, tile, const_cast<void *>(src_device), nbytes, false, false);
 }
 
 int rt_counters_read(rt_ctx *c, rt_counters *out) {

@@ -65,7 +65,7 @@ class Timings(ctypes.Structure):
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_upload", "rt_set_table", "rt_download", "rt_resize",
            "rt_clear", "rt_trace", "rt_trace_batch", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
-           "rt_readback_rect_device", "rt_write_rect_device", "rt_write_image", "rt_image_pixel_bytes",
+           "rt_readback_rect_device", "rt_write_rect_device", "rt_write_rect_device_async", "rt_write_image", "rt_image_pixel_bytes",
            "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
            "rt_work_group_size", "rt_version"]
 
@@ -100,6 +100,7 @@ def lib():
         L.rt_readback.argtypes = [vp, i32, vp, sz]
         L.rt_readback_rect_device.argtypes = [vp, i32, rp, vp, sz]
         L.rt_write_rect_device.argtypes = [vp, i32, rp, vp, sz]
+        L.rt_write_rect_device_async.argtypes = [vp, i32, rp, vp, sz]
         L.rt_write_image.argtypes = [vp, i32, vp, sz]
         L.rt_image_pixel_bytes.argtypes = [i32]
         L.rt_image_pixel_bytes.restype = sz
@@ -262,9 +263,10 @@ class Context:
         self._check(lib().rt_readback_rect_device(self._h, image, self._rect(rect), ctypes.c_void_p(device_ptr),
                                                   nbytes), "rt_readback_rect_device")
 
-    def write_rect_device(self, image, rect, device_ptr, nbytes):
-        self._check(lib().rt_write_rect_device(self._h, image, self._rect(rect), ctypes.c_void_p(device_ptr),
-                                               nbytes), "rt_write_rect_device")
+    def write_rect_device(self, image, rect, device_ptr, nbytes, wait=True):
+        """wait=False only queues the copy: the source must stay valid until sync() or another blocking call."""
+        f = lib().rt_write_rect_device if wait else lib().rt_write_rect_device_async
+        self._check(f(self._h, image, self._rect(rect), ctypes.c_void_p(device_ptr), nbytes), "rt_write_rect_device")
 
     def counters(self):
         c = Counters()

@@ -90,9 +90,12 @@ class HipBackend:
             self.ctx.readback_rect_device(image, rect, t.data_ptr(), t.numel())
         return t
 
-    def write_rect(self, image, rect, tensor):
+    def write_rect(self, image, rect, tensor, wait=True):
+        """wait=False only queues the copy on the context's stream: the caller keeps `tensor` alive and unchanged
+        until the context has been synchronised (TiledFrame.gather does)."""
         if tensor.numel():
-            self.ctx.write_rect_device(image, rect, tensor.contiguous().data_ptr(), tensor.numel())
+            assert wait or tensor.is_contiguous()
+            self.ctx.write_rect_device(image, rect, tensor.contiguous().data_ptr(), tensor.numel(), wait=wait)
 
 
 class TiledFrame:
@@ -106,6 +109,7 @@ class TiledFrame:
         self.traced = grow_rect(self.tile, backend.halo, width, height)
         self.max_cols, self.max_rows = -(-width // self.grid[0]), -(-height // self.grid[1])
         self._pad = self._recv = None
+        self._pasting = []
 
     def render(self, frame=0):
         """Trace tile + halo, filter the tile.  No communication."""
@@ -137,8 +141,18 @@ class TiledFrame:
             # finished before rank 0 pastes the strips, and before the next frame re-uses the staging memory
             torch.cuda.current_stream(pad.device).synchronize()
         if self.rank == 0:
+            # the peers' tiles are pasted with queued copies (one stream, no host round trip per tile); the tensors
+            # they read are kept until the next gather, whose read_rect synchronises the stream first
+            queued = isinstance(self.b, HipBackend)
+            self._pasting = []
             for r in range(1, self.world):
                 x0, y0, x1, y1 = tile_rect(self.width, self.height, self.world, r, self.b.halo)
                 part = recv[r][: y1 - y0, : (x1 - x0) * pb].contiguous()
-                self.b.write_rect(self.result_image, (x0, y0, x1, y1), part.to(self.b.device) if via_host else part)
+                if via_host:
+                    part = part.to(self.b.device)
+                self._pasting.append(part)
+                if queued:
+                    self.b.write_rect(self.result_image, (x0, y0, x1, y1), part, wait=False)
+                else:
+                    self.b.write_rect(self.result_image, (x0, y0, x1, y1), part)
         return recv
