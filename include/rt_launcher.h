@@ -191,6 +191,22 @@ int rt_trace(rt_ctx *ctx, const rt_trace_params *params, const rt_rect *tile);
  * per frame (reference src/main.cpp:67-69); a headless renderer that wants k spp per frame calls this. */
 int rt_trace_batch(rt_ctx *ctx, const rt_trace_params *params, int n, const rt_rect *tile);
 
+/* rt_trace_batch for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO counterpart in the reference (its GL driver allocates behind every call).
+ * Same kernels, same arguments and same images as rt_trace_batch with RT_KERNEL_TRACE3 (the wavefront pipeline), but
+ * the pipeline's scratch memory — path state, ray queue, queue counters, per-sample radiance: 408 B per path slot —
+ * is a fixed file-scope device array of the library (27.3 MB, held by every GPU the library runs on until the
+ * process ends) instead of buffers grown with hipMalloc.  The call performs no hipMalloc / hipFree / event creation
+ * and does not record profiling spans.
+ * Limit: tile pixels x n <= rt_static_max_paths() (65 536 path slots, e.g. a 256 x 256 tile at 1 sample or 128 x 128
+ * at 4); larger requests fail with RT_EINVAL and a message naming the limit.  RT_FLAG_PER_PIXEL_KERNEL and kernels
+ * other than RT_KERNEL_TRACE3 are refused (they use no scratch memory: call rt_trace_batch), maxBounces <= 30.
+ * The images (rt_resize) and the scene (rt_upload) must exist before the call, as for rt_trace_batch.
+ * All calls on one GPU share that GPU's array, from every context of the process: calls that overlap on one GPU
+ * (two contexts, or one context on two streams) race; calls queued on one stream are ordered and safe. */
+int rt_trace_batch_static(rt_ctx *ctx, const rt_trace_params *params, int n, const rt_rect *tile);
+int rt_static_max_paths(void);
+
 /* Filter::filter: `iterations` à-trous passes over the colour image using the normal / position
  * images.  With a tile, every pass covers the tile grown by the step widths of the passes that
  * follow it, so the tile's final pixels equal those of a whole-image filter as long as the colour

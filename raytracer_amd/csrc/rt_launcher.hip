@@ -30,6 +30,31 @@ hipError_t rtLaunchTonemap(const float4 *colorF32, const uint2 *colorF16, uint32
                            float exposure, hipStream_t stream);
 int rtAtrousMaxStep();
 
+// ---------------------------------------------------------------------------------------------------------------
+// rt_trace_batch_static (include/rt_launcher.h): the wavefront pipeline's path state, ray queue and counters live in
+// this file-scope device array instead of hipMalloc'ed memory.  Every GPU the library runs on holds its own copy of
+// the array (at its own address) until the process ends.  In host code the NAME of the array is only a stand-in:
+// its device address is looked up once per device in rt_create (hipGetSymbolAddress, with that device current) and
+// kept in rtStaticScratchPtr[]; host code uses that pointer, never the name.
+#define RT_STATIC_MAX_PATHS 65536 // path slots = tile pixels x samples of one call
+#define RT_STATIC_ALIGN 256
+namespace {
+constexpr size_t alignUp(size_t v) { return (v + RT_STATIC_ALIGN - 1) / RT_STATIC_ALIGN * RT_STATIC_ALIGN; }
+// carve-up of the array: (bytes per path slot) x RT_STATIC_MAX_PATHS per region, each region 256-B aligned
+constexpr size_t kStaticState16 = alignUp((size_t)RT_STATIC_MAX_PATHS * 16);      // L_seed, beta, betaOld, f1w1, f2w2, pdfs, pathStats
+constexpr size_t kStaticState8 = alignUp((size_t)RT_STATIC_MAX_PATHS * 8);        // pixSample
+constexpr size_t kStaticRay16 = alignUp((size_t)3 * RT_STATIC_MAX_PATHS * 16);    // rayO[2], rayD[2], rayHit
+constexpr size_t kStaticRay8 = alignUp((size_t)3 * RT_STATIC_MAX_PATHS * 8);      // rayWork
+constexpr size_t kStaticQueue = alignUp((size_t)RT_STATIC_MAX_PATHS * 4);         // queue[2]
+constexpr size_t kStaticCounts = alignUp(64 * sizeof(int));
+constexpr size_t kStaticRadiance = alignUp((size_t)RT_STATIC_MAX_PATHS * 16);
+constexpr size_t kStaticBytes = 7 * kStaticState16 + kStaticState8 + 5 * kStaticRay16 + kStaticRay8 + 2 * kStaticQueue +
+                                kStaticCounts + kStaticRadiance;
+} // namespace
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+#define RT_MAX_DEVICES 64
+static void *rtStaticScratchPtr[RT_MAX_DEVICES]; // device address of `scratch` on device d, set by rt_create
+
 namespace {
 
 struct DevBuf {
@@ -169,11 +194,28 @@ int drainSpans(rt_ctx *c) {
     return RT_OK;
 }
 
+// Fold the spans that have already finished (oldest first, stops at the first one still running): never blocks.
+void foldFinishedSpans(rt_ctx *c) {
+    size_t done = 0;
+    for (; done < c->spans.size(); ++done) {
+        TimedSpan &s = c->spans[done];
+        if (hipEventQuery(s.stop) != hipSuccess) break;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, s.start, s.stop) == hipSuccess) {
+            c->accMs[s.kind] += ms;
+            c->accN[s.kind] += 1;
+        }
+        c->eventPool.push_back(s.start);
+        c->eventPool.push_back(s.stop);
+    }
+    c->spans.erase(c->spans.begin(), c->spans.begin() + done);
+}
+
 struct SpanGuard { // records start on construction, stop on end()
     rt_ctx *c;
     TimedSpan s;
     bool on;
-    SpanGuard(rt_ctx *c, int kind) : c(c), on(c->profile) {
+    SpanGuard(rt_ctx *c, int kind, bool enable = true) : c(c), on(c->profile && enable) {
         if (on) {
             s.kind = kind;
             s.start = takeEvent(c);
@@ -186,6 +228,13 @@ struct SpanGuard { // records start on construction, stop on end()
             (void)hipEventRecord(s.stop, c->stream);
             c->spans.push_back(s);
             on = false;
+            if (c->spans.size() > 8192) foldFinishedSpans(c); // a caller that never reads the timings
+        }
+    }
+    ~SpanGuard() { // an early error return: the two events go back to the pool
+        if (on) {
+            c->eventPool.push_back(s.start);
+            c->eventPool.push_back(s.stop);
         }
     }
 };
@@ -238,7 +287,7 @@ ImageRef imageOf(rt_ctx *c, int image) {
 
 extern "C" {
 
-const char *rt_version(void) { return "raytracer_amd gfx950 launcher 0.1 (round 1)"; }
+const char *rt_version(void) { return "raytracer_amd gfx950 launcher 0.2 (round 2)"; }
 
 void rt_work_group_size(int kernel, int out_xyz[3]) {
     (void)kernel;
@@ -270,6 +319,18 @@ int rt_create(int device_id, rt_ctx **out) {
         return RT_ENODEV;
     }
     c->stream = c->ownStream;
+    // Device address of the static scratch array on THIS device (each GPU holds its own copy): looked up once per
+    // device, with that device current, and used from then on wherever host code needs the array's memory.
+    if (device_id < RT_MAX_DEVICES && !rtStaticScratchPtr[device_id]) {
+        void *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            (void)hipStreamDestroy(c->ownStream);
+            delete c;
+            return RT_ENODEV;
+        }
+        rtStaticScratchPtr[device_id] = ptr;
+    }
     if (const char *e = std::getenv("RT_WF_REFILL")) c->tuneRefillLanes = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_CACHE_NODES")) c->tuneCacheNodes = std::max(0, std::min(3800, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_RAYS_PER_WAVE")) c->tuneRaysPerWave = std::max(0, std::min(64, std::atoi(e)));
@@ -345,16 +406,20 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
         std::vector<int2> leaves(n);
         long long maxEnd = 0;
         int maxLeaf = 0;
-        bool leafLinksEqual = true;
+        bool leafLinksEqual = true, innerEndsWalk = false;
         for (size_t i = 0; i < n; ++i) { // can the leaf range share the record with the links? (rt_device.h)
             const RtNode48 &s = src[i];
             if (s.numTris > 0) {
                 maxLeaf = std::max(maxLeaf, s.numTris);
                 if (s.hitNext != s.missNext) leafLinksEqual = false;
                 if (s.firstTri >= 0 && (long long)s.firstTri + s.numTris > maxEnd) maxEnd = (long long)s.firstTri + s.numTris;
+            } else if (s.hitNext < 0) {
+                // an inner / empty node whose hit link ends the walk (e.g. a lone empty root): in the packed record
+                // w1 = hitNext = -1 would read as a leaf marker, so such a stream keeps the plain form
+                innerEndsWalk = true;
             }
         }
-        const bool packed = leafLinksEqual && maxLeaf <= 32 && maxEnd <= (1ll << 26);
+        const bool packed = leafLinksEqual && !innerEndsWalk && maxLeaf <= 32 && maxEnd <= (1ll << 26);
         maxEnd = 0;
         for (size_t i = 0; i < n; ++i) {
             const RtNode48 &s = src[i];
@@ -559,6 +624,103 @@ bool sameExceptPerSample(const rt_trace_params &a, const rt_trace_params &b) {
 
 } // namespace
 
+namespace {
+
+// One frame (a batch of n samples) of the wavefront pipeline over tile r with the path state in `wf`.
+// noAlloc: called by rt_trace_batch_static — nothing here may allocate (no event creation either), so the launch is
+// neither profiled nor used to time the WalkTune candidates; the schedule that is picked cannot change the picture.
+int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rect &r, const RtScene &sc,
+                   const RtImages &img, WfBuffers &wf, bool noAlloc) {
+    const rt_trace_params *p = &params[0];
+    const size_t hot = c->boxes.bytes + c->leaves.bytes + c->tris48.bytes;
+    const int xcdRemap = hot > (size_t)3 * 1024 * 1024;
+    const size_t tilePixels = (size_t)(r.x1 - r.x0) * (size_t)(r.y1 - r.y0);
+    wf.tilePixels = (int)tilePixels;
+    WfParams wp;
+    std::memset(&wp, 0, sizeof wp);
+    std::memcpy(wp.eye, p->eye, sizeof wp.eye);
+    std::memcpy(wp.ray00, p->ray00, sizeof wp.ray00);
+    std::memcpy(wp.ray01, p->ray01, sizeof wp.ray01);
+    std::memcpy(wp.ray10, p->ray10, sizeof wp.ray10);
+    std::memcpy(wp.ray11, p->ray11, sizeof wp.ray11);
+    wp.maxBounces = p->maxBounces;
+    wp.numEmitters = p->numEmitters;
+    // A walk over a threaded tree visits a node at most once, so numNodes visits are enough for any stream the
+    // reference's builder can make; the cap keeps a stream with cyclic links (which rt_upload's range check cannot
+    // see) from occupying the GPU for as long as the caller's maxFollows allows.
+    wp.maxFollows = std::min(p->maxFollows > 0 ? p->maxFollows : 1000, std::max(c->numNodes, 1));
+    wp.flags = p->flags;
+    wp.batch = n;
+    // a wave takes new rays when all its lanes are free (neighbouring rays stay together: vector-L1 locality) —
+    // or, when the scene is beyond the L2s and there is no locality to keep, as soon as half of them are
+    wp.refillLanes = c->tuneRefillLanes > 0 ? c->tuneRefillLanes : (hot > (size_t)3 * 1024 * 1024 ? 32 : 64);
+    wp.extendBlocksPerCU = c->tuneExtendBlocks;
+    wp.primaryBlocksPerCU = c->tunePrimaryBlocks;
+    wp.primaryViaExtend = c->tunePrimaryVia >= 0 ? c->tunePrimaryVia : (hot > (size_t)3 * 1024 * 1024 ? 1 : 0);
+    wp.extendCacheNodes = c->tuneCacheNodes;
+    wp.extendRaysPerWave = c->tuneRaysPerWave;
+    wp.extendFill = c->tuneFill;
+    wp.extendMinRays = c->tuneMinRays;
+    // beyond the L2s every walk step is a trip to memory: stop the walk phase early at any wave width;
+    // L2-resident scenes: only while the wave is (nearly) full
+    const bool beyondL2 = hot > (size_t)3 * 1024 * 1024;
+    wp.walkStop = c->tuneWalkStop > 0 ? c->tuneWalkStop : (beyondL2 ? 3 : 8);
+    wp.walkMin = c->tuneWalkMin > 0 ? c->tuneWalkMin : (beyondL2 ? 1 : 40);
+    rt_ctx::WalkTune &wt = c->walkTune;
+    const bool tuning = !noAlloc && c->tuneWalkStop == 0 && !beyondL2 && tilePixels * (size_t)n >= ((size_t)1 << 20);
+    if (tuning) {
+        if (wt.pending) { // the frame timed by the previous call (blocks only during the first three frames)
+            float ms = 0.0f;
+            HIP_TRY(c, hipEventSynchronize(wt.ev[1]));
+            HIP_TRY(c, hipEventElapsedTime(&ms, wt.ev[0], wt.ev[1]));
+            wt.pending = false;
+            if (wt.state == 1) {
+                wt.msWhole = ms;
+                wt.state = 2;
+            } else if (wt.state == 2) {
+                wt.choice = ms < 0.97f * wt.msWhole ? 1 : 8;
+                wt.state = 3;
+            }
+        }
+        wp.walkStop = wt.state == 2 ? 1 : wt.state == 3 ? wt.choice : 8;
+    }
+    wp.extendChunk = c->tuneChunk;
+    // full waves test their leaves cooperatively when the triangles do not fit the L2s (measured on MI355X: the
+    // coalesced triangle reads of that scheme win on the 1.7 M-triangle lattice, 3.66 -> 3.28 ms, and lose to
+    // lane-by-lane testing on L2-resident room.obj, 41.4 -> 48.9 ms)
+    wp.extendCoop = c->tuneCoop >= 0 ? c->tuneCoop : (hot > (size_t)3 * 1024 * 1024 ? 1 : 2);
+    wp.coopA = c->tuneCoopA;
+    wp.coopB = c->tuneCoopB;
+    for (int k = 0; k < n; ++k) {
+        wp.s[k].time = params[k].time;
+        wp.s[k].blendFactor = params[k].blendFactor;
+        wp.s[k].oob0 = params[k].oobSeeds[0];
+        wp.s[k].oob1 = params[k].oobSeeds[1];
+        wp.s[k].oob2 = params[k].oobSeeds[2];
+    }
+    const bool timeIt = tuning && (wt.state == 1 || wt.state == 2);
+    if (timeIt) {
+        if (!wt.ev[0]) wt.ev[0] = takeEvent(c);
+        if (!wt.ev[1]) wt.ev[1] = takeEvent(c);
+        HIP_TRY(c, hipEventRecord(wt.ev[0], c->stream));
+    }
+    const bool profiled = c->profile && !noAlloc;
+    rt_ctx *spanCtx = c;
+    SpanGuard span(spanCtx, TK_TRACE, profiled);
+    hipError_t e = rtLaunchWavefront(sc, img, wp, wf, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream,
+                                     profiled ? c : nullptr);
+    span.end();
+    if (timeIt) {
+        HIP_TRY(c, hipEventRecord(wt.ev[1], c->stream));
+        wt.pending = true;
+    }
+    if (tuning && wt.state == 0) wt.state = 1;
+    if (e != hipSuccess) return hipFail(c, e, "wavefront launch");
+    return RT_OK;
+}
+
+} // namespace
+
 int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rect *tile) {
     if (!c || !params) return RT_EINVAL;
     if (n < 1 || n > WF_MAX_BATCH) return fail(c, RT_EINVAL, "rt_trace_batch: n must be 1..16");
@@ -595,7 +757,9 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         if (perPixel) {
             for (int k = 0; k < n; ++k) {
                 SpanGuard span(c, TK_TRACE), span2(c, RT_TIME_PER_PIXEL);
-                hipError_t e = rtLaunchTrace3(sc, img, params[k], r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream);
+                rt_trace_params pk = params[k];
+                pk.maxFollows = std::min(pk.maxFollows > 0 ? pk.maxFollows : 1000, std::max(c->numNodes, 1)); // see wavefrontFrame
+                hipError_t e = rtLaunchTrace3(sc, img, pk, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream);
                 span2.end();
                 span.end();
                 if (e != hipSuccess) return hipFail(c, e, "trace3 launch");
@@ -604,83 +768,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         }
         WfBuffers wf;
         if ((rc = ensureWavefront(c, tilePixels * (size_t)n, tilePixels * (size_t)n, wf))) return rc;
-        wf.tilePixels = (int)tilePixels;
-        WfParams wp;
-        std::memset(&wp, 0, sizeof wp);
-        std::memcpy(wp.eye, p->eye, sizeof wp.eye);
-        std::memcpy(wp.ray00, p->ray00, sizeof wp.ray00);
-        std::memcpy(wp.ray01, p->ray01, sizeof wp.ray01);
-        std::memcpy(wp.ray10, p->ray10, sizeof wp.ray10);
-        std::memcpy(wp.ray11, p->ray11, sizeof wp.ray11);
-        wp.maxBounces = p->maxBounces;
-        wp.numEmitters = p->numEmitters;
-        wp.maxFollows = p->maxFollows > 0 ? p->maxFollows : 1000;
-        wp.flags = p->flags;
-        wp.batch = n;
-        // a wave takes new rays when all its lanes are free (neighbouring rays stay together: vector-L1 locality) —
-        // or, when the scene is beyond the L2s and there is no locality to keep, as soon as half of them are
-        wp.refillLanes = c->tuneRefillLanes > 0 ? c->tuneRefillLanes : (hot > (size_t)3 * 1024 * 1024 ? 32 : 64);
-        wp.extendBlocksPerCU = c->tuneExtendBlocks;
-        wp.primaryBlocksPerCU = c->tunePrimaryBlocks;
-        wp.primaryViaExtend = c->tunePrimaryVia >= 0 ? c->tunePrimaryVia : (hot > (size_t)3 * 1024 * 1024 ? 1 : 0);
-        wp.extendCacheNodes = c->tuneCacheNodes;
-        wp.extendRaysPerWave = c->tuneRaysPerWave;
-        wp.extendFill = c->tuneFill;
-        wp.extendMinRays = c->tuneMinRays;
-        // beyond the L2s every walk step is a trip to memory: stop the walk phase early at any wave width;
-        // L2-resident scenes: only while the wave is (nearly) full
-        const bool beyondL2 = hot > (size_t)3 * 1024 * 1024;
-        wp.walkStop = c->tuneWalkStop > 0 ? c->tuneWalkStop : (beyondL2 ? 3 : 8);
-        wp.walkMin = c->tuneWalkMin > 0 ? c->tuneWalkMin : (beyondL2 ? 1 : 40);
-        rt_ctx::WalkTune &wt = c->walkTune;
-        const bool tuning = c->tuneWalkStop == 0 && !beyondL2 && tilePixels * (size_t)n >= ((size_t)1 << 20);
-        if (tuning) {
-            if (wt.pending) { // the frame timed by the previous call (blocks only during the first three frames)
-                float ms = 0.0f;
-                HIP_TRY(c, hipEventSynchronize(wt.ev[1]));
-                HIP_TRY(c, hipEventElapsedTime(&ms, wt.ev[0], wt.ev[1]));
-                wt.pending = false;
-                if (wt.state == 1) {
-                    wt.msWhole = ms;
-                    wt.state = 2;
-                } else if (wt.state == 2) {
-                    wt.choice = ms < 0.97f * wt.msWhole ? 1 : 8;
-                    wt.state = 3;
-                }
-            }
-            wp.walkStop = wt.state == 2 ? 1 : wt.state == 3 ? wt.choice : 8;
-        }
-        wp.extendChunk = c->tuneChunk;
-        // full waves test their leaves cooperatively when the triangles do not fit the L2s (measured on MI355X: the
-        // coalesced triangle reads of that scheme win on the 1.7 M-triangle lattice, 3.66 -> 3.28 ms, and lose to
-        // lane-by-lane testing on L2-resident room.obj, 41.4 -> 48.9 ms)
-        wp.extendCoop = c->tuneCoop >= 0 ? c->tuneCoop : (hot > (size_t)3 * 1024 * 1024 ? 1 : 2);
-        wp.coopA = c->tuneCoopA;
-        wp.coopB = c->tuneCoopB;
-        for (int k = 0; k < n; ++k) {
-            wp.s[k].time = params[k].time;
-            wp.s[k].blendFactor = params[k].blendFactor;
-            wp.s[k].oob0 = params[k].oobSeeds[0];
-            wp.s[k].oob1 = params[k].oobSeeds[1];
-            wp.s[k].oob2 = params[k].oobSeeds[2];
-        }
-        const bool timeIt = tuning && (wt.state == 1 || wt.state == 2);
-        if (timeIt) {
-            if (!wt.ev[0]) wt.ev[0] = takeEvent(c);
-            if (!wt.ev[1]) wt.ev[1] = takeEvent(c);
-            HIP_TRY(c, hipEventRecord(wt.ev[0], c->stream));
-        }
-        SpanGuard span(c, TK_TRACE);
-        hipError_t e = rtLaunchWavefront(sc, img, wp, wf, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream,
-                                         c->profile ? c : nullptr);
-        span.end();
-        if (timeIt) {
-            HIP_TRY(c, hipEventRecord(wt.ev[1], c->stream));
-            wt.pending = true;
-        }
-        if (tuning && wt.state == 0) wt.state = 1;
-        if (e != hipSuccess) return hipFail(c, e, "wavefront launch");
-        return RT_OK;
+        return wavefrontFrame(c, params, n, r, sc, img, wf, false);
     }
     case RT_KERNEL_TRACE3_RL: {
         // traceRL (reference trace3.cs:695-791): the scene of trace3 plus the Q-table state of slots 7..10.
@@ -767,6 +855,74 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
 }
 
 int rt_trace(rt_ctx *c, const rt_trace_params *p, const rt_rect *tile) { return rt_trace_batch(c, p, 1, tile); }
+
+int rt_static_max_paths(void) { return RT_STATIC_MAX_PATHS; }
+
+// rt_trace_batch for callers that cannot allocate (include/rt_launcher.h): the same kernels, launched with the
+// pipeline's scratch memory carved out of the file-scope array `scratch` — through the device address kept per
+// device at rt_create, never through the array's name — instead of hipMalloc'ed buffers.  No hipMalloc / hipFree /
+// event creation on this path; every call on a GPU shares that GPU's array (overlapping calls race).
+int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const rt_rect *tile) {
+    if (!c || !params) return RT_EINVAL;
+    if (n < 1 || n > WF_MAX_BATCH) return fail(c, RT_EINVAL, "rt_trace_batch_static: n must be 1..16");
+    const rt_trace_params *p = &params[0];
+    for (int k = 0; k < n; ++k) {
+        if (params[k].size != sizeof(rt_trace_params)) return fail(c, RT_EINVAL, "rt_trace_batch_static: params.size mismatch");
+        if (k && !sameExceptPerSample(params[0], params[k]))
+            return fail(c, RT_EINVAL, "rt_trace_batch_static: entries may differ only in time, blendFactor, frameIndex, oobSeeds");
+    }
+    if (p->kernel != RT_KERNEL_TRACE3 || (p->flags & RT_FLAG_PER_PIXEL_KERNEL))
+        return fail(c, RT_EINVAL, "rt_trace_batch_static: only the wavefront pipeline of RT_KERNEL_TRACE3 uses scratch memory");
+    if (!c->color.p) return fail(c, RT_ESTATE, "rt_trace_batch_static: no images (call rt_resize)");
+    const rt_rect r = tile ? *tile : fullRect(c);
+    if (!rectOk(c, r)) return fail(c, RT_EINVAL, "rt_trace_batch_static: tile outside the image");
+    if (p->maxBounces < 0 || p->maxBounces > 30) return fail(c, RT_EINVAL, "rt_trace_batch_static: maxBounces must be 0..30");
+    if ((p->flags & RT_FLAG_WATERTIGHT) && (p->flags & RT_FLAG_FAST_SHADOWS))
+        return fail(c, RT_EINVAL, "rt_trace: RT_FLAG_WATERTIGHT and RT_FLAG_FAST_SHADOWS cannot be combined");
+    if (!c->boxes.p || !c->tris48.p || !c->mtls.p)
+        return fail(c, RT_ESTATE, "rt_trace_batch_static: nodes, triangles and materials must be uploaded first");
+    if (c->maxTriEnd > c->numTris)
+        return fail(c, RT_ECORRUPT, "rt_trace_batch_static: a leaf references triangles beyond the uploaded triangle stream");
+    const size_t tilePixels = (size_t)(r.x1 - r.x0) * (size_t)(r.y1 - r.y0);
+    if (tilePixels * (size_t)n > (size_t)RT_STATIC_MAX_PATHS)
+        return fail(c, RT_EINVAL, "rt_trace_batch_static: tile pixels x samples = " + std::to_string(tilePixels * (size_t)n) +
+                                      " exceeds the static scratch limit of " + std::to_string(RT_STATIC_MAX_PATHS) +
+                                      " path slots (use rt_trace_batch, or a smaller tile / fewer samples per call)");
+    if (tilePixels == 0) return RT_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    unsigned char *base = c->device < RT_MAX_DEVICES ? (unsigned char *)rtStaticScratchPtr[c->device] : nullptr;
+    if (!base) return fail(c, RT_ESTATE, "rt_trace_batch_static: the static scratch array was not resolved on this device");
+    RtScene sc;
+    RtImages img;
+    fillScene(c, sc, img);
+    // carve-up (the order of kStaticBytes above)
+    size_t off = 0;
+    auto take = [&](size_t bytes) { unsigned char *q = base + off; off += bytes; return q; };
+    WfBuffers wf;
+    wf.L_seed = (float4 *)take(kStaticState16);
+    wf.beta = (float4 *)take(kStaticState16);
+    wf.betaOld = (float4 *)take(kStaticState16);
+    wf.f1w1 = (float4 *)take(kStaticState16);
+    wf.f2w2 = (float4 *)take(kStaticState16);
+    wf.pdfs = (float4 *)take(kStaticState16);
+    wf.pathStats = (int4 *)take(kStaticState16);
+    wf.pixSample = (uint2 *)take(kStaticState8);
+    wf.rayO[0] = (float4 *)take(kStaticRay16);
+    wf.rayO[1] = (float4 *)take(kStaticRay16);
+    wf.rayD[0] = (float4 *)take(kStaticRay16);
+    wf.rayD[1] = (float4 *)take(kStaticRay16);
+    wf.rayHit = (int4 *)take(kStaticRay16);
+    wf.rayWork = (int2 *)take(kStaticRay8);
+    wf.queue[0] = (int *)take(kStaticQueue);
+    wf.queue[1] = (int *)take(kStaticQueue);
+    wf.counts = (int *)take(kStaticCounts);
+    wf.radiance = (float4 *)take(kStaticRadiance);
+    if (off != kStaticBytes) return fail(c, RT_ESTATE, "rt_trace_batch_static: scratch carve-up mismatch");
+    wf.capacity = RT_STATIC_MAX_PATHS;
+    // (the queue counters, the only words that must start at zero, are cleared by the launch: hipMemsetAsync on wf.counts)
+    return wavefrontFrame(c, params, n, r, sc, img, wf, true);
+}
 
 int rt_filter_halo(int iterations) {
     int h = 0;

@@ -64,7 +64,7 @@ class Timings(ctypes.Structure):
 
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_upload", "rt_set_table", "rt_download", "rt_resize",
-           "rt_clear", "rt_trace", "rt_trace_batch", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
+           "rt_clear", "rt_trace", "rt_trace_batch", "rt_trace_batch_static", "rt_static_max_paths", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
            "rt_readback_rect_device", "rt_write_rect_device", "rt_write_rect_device_async", "rt_write_image", "rt_image_pixel_bytes",
            "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
            "rt_work_group_size", "rt_version"]
@@ -94,6 +94,8 @@ def lib():
         L.rt_clear.argtypes = [vp]
         L.rt_trace.argtypes = [vp, ctypes.POINTER(TraceParams), rp]
         L.rt_trace_batch.argtypes = [vp, ctypes.POINTER(TraceParams), i32, rp]
+        L.rt_trace_batch_static.argtypes = [vp, ctypes.POINTER(TraceParams), i32, rp]
+        L.rt_static_max_paths.argtypes = []
         L.rt_filter.argtypes = [vp, i32, fl, fl, fl, rp]
         L.rt_filter_halo.argtypes = [i32]
         L.rt_tonemap.argtypes = [vp, i32, fl, rp]
@@ -216,13 +218,18 @@ class Context:
     def trace(self, params, rect=None):
         self._check(lib().rt_trace(self._h, ctypes.byref(params), self._rect(rect)), "rt_trace")
 
-    def trace_batch(self, params_list, rect=None):
+    def trace_batch(self, params_list, rect=None, static=False):
+        """static=True: rt_trace_batch_static, the variant that allocates nothing (scratch memory in a fixed device
+        array of the library; tile pixels x samples <= rt_static_max_paths())."""
         arr = (TraceParams * len(params_list))(*params_list)
-        self._check(lib().rt_trace_batch(self._h, arr, len(params_list), self._rect(rect)), "rt_trace_batch")
+        if static:
+            self._check(lib().rt_trace_batch_static(self._h, arr, len(params_list), self._rect(rect)), "rt_trace_batch_static")
+        else:
+            self._check(lib().rt_trace_batch(self._h, arr, len(params_list), self._rect(rect)), "rt_trace_batch")
 
     def trace_samples(self, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.0625, max_bounces=5, flags=0,
                       rect=None, num_emitters=None, oob="llvmpipe", max_follows=1000, batch=MAX_BATCH,
-                      kernel=KERNEL_TRACE3, **uniforms):
+                      kernel=KERNEL_TRACE3, static=False, **uniforms):
         """spp dispatches with time_k = time0 + dtime*k, blendFactor_k = k/(k+1) and frameIndex_k = k, issued in
         groups of up to `batch` concurrent samples (rt_trace_batch; batch=1 issues one rt_trace per sample).
         `uniforms`: importance, mis, use_blue_noise, phong_exponent, specular_factor, roughness."""
@@ -239,7 +246,7 @@ class Context:
                 self.trace(p, rect)
         else:
             for i in range(0, spp, batch):
-                self.trace_batch(plist[i:i + batch], rect)
+                self.trace_batch(plist[i:i + batch], rect, static=static)
 
     def filter(self, iterations, c_phi0=3.3, n_phi0=1e-2, p_phi0=5.5, rect=None):
         self._check(lib().rt_filter(self._h, iterations, c_phi0, n_phi0, p_phi0, self._rect(rect)), "rt_filter")
