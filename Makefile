@@ -21,7 +21,7 @@ ORCFLAGS  := -std=c11 -O2 -fPIC -ffp-contract=off -fno-fast-math -fopenmp -Wall 
              -I$(ROOT)/include
 
 HOST_SRCS := $(HOSTDIR)/scene.cpp $(HOSTDIR)/png_write.cpp $(HOSTDIR)/host_cabi.cpp $(HOSTDIR)/render.cpp \
-             $(HOSTDIR)/rt_loader.cpp
+             $(HOSTDIR)/rt_loader.cpp $(HOSTDIR)/glfw_setter.cpp
 HOST_HDRS := $(wildcard $(HOSTDIR)/*.hpp) $(wildcard $(ROOT)/include/*.h)
 HIP_SRCS  := $(wildcard $(CSRC)/*.hip)
 HIP_HDRS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) $(wildcard $(ROOT)/include/*.h)
@@ -39,7 +39,7 @@ $(LIBDIR)/librt_host.so: $(HOST_SRCS) $(HOST_HDRS)
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRCS) -ldl
 
 $(LIBDIR)/rt_headless: $(HOSTDIR)/main.cpp $(LIBDIR)/librt_host.so
-	$(CXX) $(HOSTFLAGS) -o $@ $(HOSTDIR)/main.cpp -L$(LIBDIR) -lrt_host -Wl,-rpath,'$$ORIGIN' -ldl
+	$(CXX) $(HOSTFLAGS) -o $@ $(HOSTDIR)/main.cpp -L$(LIBDIR) -lrt_host -Wl,-rpath,'$$ORIGIN' -ldl -lpthread
 
 $(LIBDIR)/librt_hip.so: $(HIP_SRCS) $(HIP_HDRS)
 	@mkdir -p $(LIBDIR)

@@ -74,6 +74,17 @@ void rth_scene_free(rth_scene *s);
 int rth_camera_rays(const float eye[3], const float look_at[3], const float up[3], float fov_deg, float width,
                     float height, float z_near, float z_far, float out_rays[12]);
 
+/* Multi-GPU tiling rule of the headless host (raytracer_amd/host/tiling.hpp; no counterpart in the single-GPU
+ * reference): rank's tile [x0,x1) x [y0,y1) of a width x height frame split over `world` GPUs when the filter halo is
+ * `halo` pixels.  out_rect = {x0, y0, x1, y1}; out_grid (may be NULL) = {columns, rows}. */
+int rth_tile_rect(int width, int height, int world, int rank, int halo, int32_t out_rect[4], int32_t out_grid[2]);
+
+/* The state machine of the reference's input handler (reference src/glfw_setter.cpp:77-237,304-310) applied to one
+ * scripted event: key = a GLFW key code (printable keys: their ASCII code) or 0 with scroll != 0 for a scroll event.
+ * state = {eye[3], lookAt[3], up[3], fov, exposure} (11 floats, in/out); ints = {frameNumber, maxBounces, iterations,
+ * filterOn} (in/out).  Returns 0. */
+int rth_input_event(int key, double scroll, float state[11], int32_t ints[4]);
+
 /* FrameBuffer::saveToImage (reference src/FrameBuffer.cpp:89-107): 8-bit RGBA PNG, rows
  * flipped vertically when flip != 0. */
 int rth_write_png(const char *path, int width, int height, const uint8_t *rgba, int flip);

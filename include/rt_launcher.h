@@ -156,7 +156,8 @@ enum rt_image {
     RT_IMAGE_TRIDX = 4,    /* int32 primary-hit triangle index (RT_FLAG_AUX)                    */
     RT_IMAGE_VISITS = 5,   /* int32 node-visit count of the primary traversal (RT_FLAG_AUX)     */
     RT_IMAGE_STATS = 6,    /* 4 x int32 per pixel (RT_FLAG_PIXEL_STATS)                         */
-    RT_IMAGE_LDR = 7       /* RGBA8 result of rt_tonemap                                        */
+    RT_IMAGE_LDR = 7,      /* RGBA8 result of rt_tonemap                                        */
+    RT_IMAGE_ASSEMBLED = 8 /* root rank: the frame rt_gather_tiles last put together (pixel format of the gathered image) */
 };
 
 int rt_create(int device_id, rt_ctx **out);
@@ -230,6 +231,32 @@ int rt_write_rect_device(rt_ctx *ctx, int image, const rt_rect *tile, const void
 int rt_write_rect_device_async(rt_ctx *ctx, int image, const rt_rect *tile, const void *src_device, size_t nbytes);
 int rt_write_image(rt_ctx *ctx, int image, const void *src_host, size_t nbytes);
 size_t rt_image_pixel_bytes(int image);
+
+/* ---- Multi-GPU: screen-space tiles, scene replicated, ONE gather of the finished tiles (no counterpart in the reference,
+ * which is a single-GPU program).  One rt_ctx per GPU, each with a rank in an RCCL communicator; ranks may be
+ * processes (one per GPU, e.g. under torch.distributed.run) or threads of one process (one per GPU, rt_headless --gpus N).
+ * RCCL is opened at run time (librccl.so.1) by rt_comm_unique_id / rt_comm_init, so single-GPU users never load it.
+ *   rt_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by any means
+ *   rt_comm_init        ncclCommInitRank on the context's device; with nranks == 1 and id == NULL no communicator is made
+ *                       (local mode: rt_gather_tiles then only copies the context's own tile)
+ *   rt_gather_tiles     rects[r] (nrects == nranks, the same list on every rank, a partition of the frame) is the tile rank r
+ *                       owns of `image`.  Every rank packs its tile into pre-allocated staging memory on the context's
+ *                       stream; the sends / receives (one ncclGroup: every peer sends over its own xGMI link, no ring) and,
+ *                       on `root`, the pasting into RT_IMAGE_ASSEMBLED run on a second stream ordered by events — no host
+ *                       wait anywhere, so the call returns at once and the next frame's rt_trace overlaps the gather.
+ *                       Staging is double-buffered: gather k+2 waits (on the device) for gather k.
+ *                       RT_IMAGE_ASSEMBLED always holds the most recently gathered frame; rt_readback of it waits for it.
+ * Allocation happens only when a tile grows beyond what earlier calls have seen (normally: the first two calls). */
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(void *id, size_t nbytes);
+int rt_comm_init(rt_ctx *ctx, int nranks, int rank, const void *id, size_t nbytes);
+int rt_comm_destroy(rt_ctx *ctx);
+int rt_gather_tiles(rt_ctx *ctx, int image, const rt_rect *rects, int nrects, int root);
+
+/* The schedule setting of the most recent rt_trace / rt_trace_batch of RT_KERNEL_TRACE3 ("Scheduling"):
+ * 0 = none yet, or that launch was one of the first frames after an upload / resize on which the launcher still times
+ * its two candidates; else the walkStop in use (eighths of the walking lanes; 8 = every lane walks to its leaf). */
+int rt_walk_stop(const rt_ctx *ctx);
 
 int rt_counters_read(rt_ctx *ctx, rt_counters *out); /* blocking */
 int rt_counters_reset(rt_ctx *ctx);

@@ -1,0 +1,177 @@
+// rt_context.h — the launcher's per-GPU context and the small helpers every translation unit of librt_hip.so that
+// implements rt_* entry points shares (rt_launcher.hip: scene / images / trace / filter; rt_comm.hip: multi-GPU
+// gather over RCCL).  Private to the library: callers only ever see the opaque rt_ctx of include/rt_launcher.h.
+#ifndef RT_CONTEXT_H
+#define RT_CONTEXT_H
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+enum TimeKind { TK_TRACE = RT_TIME_TRACE, TK_FILTER = RT_TIME_FILTER, TK_TONEMAP = RT_TIME_TONEMAP };
+
+struct TimedSpan {
+    hipEvent_t start, stop;
+    int kind;
+};
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    // scene
+    DevBuf boxes, leaves, tris48, tris128, mtls, emitters, raw[11], tables[5];
+    int numNodes = 0, numTris = 0, numMtls = 0, numEmitters = 0;
+    int maxTriEnd = 0; // largest firstTri+numTris over the nodes, checked against numTris at launch
+
+    // images
+    int width = 0, height = 0;
+    DevBuf color, normal, pos, filt[2], tridx, visits, stats, ldr;
+    int filteredIndex = -1; // which of filt[] holds the result of the last rt_filter
+
+    // wavefront path tracer state (wavefront.h), grown on demand
+    DevBuf wfState[8], wfRay[6], wfQueue[2], wfCounts, wfRadiance;
+    size_t wfCapacity = 0, wfRadianceSlots = 0;
+    int tuneRefillLanes = 0, tuneExtendBlocks = 4;  // development knobs: RT_WF_REFILL (0: by scene size), RT_WF_BLOCKS
+    bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
+    int tuneWalkStop = 0, tuneWalkMin = 0;           // RT_WF_WALK_STOP (eighths), RT_WF_WALK_MIN: 0 = by scene size (WfParams::walkStop)
+    // L2-resident scenes: whether full waves should cut their walk phases short depends on the scene (room.obj
+    // -9 %, scene.obj +10 %), so the first frames after a scene upload / resize time both settings and the
+    // launcher keeps the faster one.  The picture does not depend on it.
+    struct WalkTune {
+        int state = 0;        // 0 warm-up frame, 1 timing "walk to the end", 2 timing "stop early", 3 decided
+        bool pending = false; // walkEv[] of the frame being timed are recorded
+        float msWhole = 0.0f;
+        int choice = 8;       // walkStop in use once decided
+        hipEvent_t ev[2] = {nullptr, nullptr};
+    } walkTune;
+    int lastWalkStop = 0;      // what the most recent wavefront launch used ...
+    bool lastWalkSettled = false; // ... and whether that was a settled choice (rt_walk_stop)
+    int tuneMinRays = 4;                             // RT_WF_MIN_RAYS: floor of the rays-per-wave rule
+    int tuneCoopA = 8, tuneCoopB = 12;               // RT_WF_COOP_A / _B: the per-round rule of WfParams::coopA
+    int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 2, tuneChunk = 64, tunePrimaryBlocks = 32, tunePrimaryVia = -1;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
+    int tuneCacheNodes = 896;                        // RT_WF_CACHE_NODES: 28 KB + 12 KB of wave scratch per block, 4 blocks per CU
+
+    // multi-GPU gather over RCCL (rt_comm.hip)
+    struct Comm {
+        void *nccl = nullptr;          // ncclComm_t; null in local mode (nranks == 1, no id given)
+        int nranks = 1, rank = 0;
+        bool ready = false;            // stream + events exist
+        hipStream_t stream = nullptr;  // the collective and the pasting run here, beside the next frame's trace
+        hipEvent_t tileReady[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+        bool used[2] = {false, false}; // done[k] has been recorded at least once
+        DevBuf send[2];                // this rank's tile as packed rows, double-buffered by gather parity
+        std::vector<DevBuf> recv[2];   // root only: one buffer per peer
+        unsigned gathers = 0;          // number of rt_gather_tiles calls so far
+        int last = -1;                 // parity of the most recent gather
+    } comm;
+    DevBuf assembled;                  // root: the frame put together from every rank's tile (RT_IMAGE_ASSEMBLED)
+    size_t assembledPixelBytes = 0;
+
+    DevBuf counters;
+    bool profile = false;
+    std::vector<TimedSpan> spans;
+    std::vector<hipEvent_t> eventPool;
+    double accMs[RT_TIME_KINDS] = {};
+    uint64_t accN[RT_TIME_KINDS] = {};
+};
+
+inline int fail(rt_ctx *c, int code, const std::string &msg) {
+    if (c) c->error = msg;
+    return code;
+}
+
+inline int hipFail(rt_ctx *c, hipError_t e, const char *what) {
+    return fail(c, e == hipErrorOutOfMemory ? RT_ENOMEM : RT_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, call)                                      \
+    do {                                                        \
+        hipError_t e_ = (call);                                 \
+        if (e_ != hipSuccess) return hipFail(ctx, e_, #call);   \
+    } while (0)
+
+inline int bind(rt_ctx *c) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    return RT_OK;
+}
+
+inline int ensure(rt_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.p && b.bytes >= bytes) return RT_OK;
+    if (b.p) {
+        HIP_TRY(c, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    HIP_TRY(c, hipMalloc(&b.p, bytes));
+    b.bytes = bytes;
+    return RT_OK;
+}
+
+inline int uploadTo(rt_ctx *c, DevBuf &b, const void *src, size_t bytes) {
+    int r = ensure(c, b, bytes);
+    if (r) return r;
+    if (bytes) {
+        // the caller's buffer is only borrowed for this call: synchronous copy
+        HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return RT_OK;
+}
+
+inline void releaseBuf(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+inline hipEvent_t takeEvent(rt_ctx *c) {
+    if (!c->eventPool.empty()) {
+        hipEvent_t e = c->eventPool.back();
+        c->eventPool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+inline bool rectOk(const rt_ctx *c, const rt_rect &r) {
+    return r.x0 >= 0 && r.y0 >= 0 && r.x1 <= c->width && r.y1 <= c->height && r.x0 <= r.x1 && r.y0 <= r.y1;
+}
+
+inline rt_rect fullRect(const rt_ctx *c) { return rt_rect{0, 0, c->width, c->height}; }
+
+struct ImageRef {
+    void *p;
+    size_t pixelBytes;
+};
+
+inline ImageRef imageOf(rt_ctx *c, int image) {
+    switch (image) {
+    case RT_IMAGE_COLOR: return {c->color.p, 16};
+    case RT_IMAGE_NORMAL: return {c->normal.p, 4};
+    case RT_IMAGE_POSITION: return {c->pos.p, 8};
+    case RT_IMAGE_FILTERED: return {c->filteredIndex >= 0 ? c->filt[c->filteredIndex].p : nullptr, 8};
+    case RT_IMAGE_TRIDX: return {c->tridx.p, 4};
+    case RT_IMAGE_VISITS: return {c->visits.p, 4};
+    case RT_IMAGE_STATS: return {c->stats.p, 16};
+    case RT_IMAGE_LDR: return {c->ldr.p, 4};
+    case RT_IMAGE_ASSEMBLED: return {c->assembledPixelBytes ? c->assembled.p : nullptr, c->assembledPixelBytes};
+    default: return {nullptr, 0};
+    }
+}
+
+
+#endif

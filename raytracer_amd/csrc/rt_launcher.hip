@@ -29,6 +29,10 @@ hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const u
 hipError_t rtLaunchTonemap(const float4 *colorF32, const uint2 *colorF16, uint32_t *out, int W, const rt_rect &rect,
                            float exposure, hipStream_t stream);
 int rtAtrousMaxStep();
+// rt_comm.hip
+void rtCommQuiesce(rt_ctx *c);
+void rtCommRelease(rt_ctx *c);
+int rtCommOrderAfterGather(rt_ctx *c);
 
 // ---------------------------------------------------------------------------------------------------------------
 // rt_trace_batch_static (include/rt_launcher.h): the wavefront pipeline's path state, ray queue and counters live in
@@ -55,129 +59,9 @@ static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 #define RT_MAX_DEVICES 64
 static void *rtStaticScratchPtr[RT_MAX_DEVICES]; // device address of `scratch` on device d, set by rt_create
 
-namespace {
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-};
-
-enum TimeKind { TK_TRACE = RT_TIME_TRACE, TK_FILTER = RT_TIME_FILTER, TK_TONEMAP = RT_TIME_TONEMAP };
-
-struct TimedSpan {
-    hipEvent_t start, stop;
-    int kind;
-};
-
-} // namespace
-
-struct rt_ctx {
-    int device = 0;
-    hipStream_t ownStream = nullptr;
-    hipStream_t stream = nullptr;
-    std::string error;
-
-    // scene
-    DevBuf boxes, leaves, tris48, tris128, mtls, emitters, raw[11], tables[5];
-    int numNodes = 0, numTris = 0, numMtls = 0, numEmitters = 0;
-    int maxTriEnd = 0; // largest firstTri+numTris over the nodes, checked against numTris at launch
-
-    // images
-    int width = 0, height = 0;
-    DevBuf color, normal, pos, filt[2], tridx, visits, stats, ldr;
-    int filteredIndex = -1; // which of filt[] holds the result of the last rt_filter
-
-    // wavefront path tracer state (wavefront.h), grown on demand
-    DevBuf wfState[8], wfRay[6], wfQueue[2], wfCounts, wfRadiance;
-    size_t wfCapacity = 0, wfRadianceSlots = 0;
-    int tuneRefillLanes = 0, tuneExtendBlocks = 4;  // development knobs: RT_WF_REFILL (0: by scene size), RT_WF_BLOCKS
-    bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
-    int tuneWalkStop = 0, tuneWalkMin = 0;           // RT_WF_WALK_STOP (eighths), RT_WF_WALK_MIN: 0 = by scene size (WfParams::walkStop)
-    // L2-resident scenes: whether full waves should cut their walk phases short depends on the scene (room.obj
-    // -9 %, scene.obj +10 %), so the first frames after a scene upload / resize time both settings and the
-    // launcher keeps the faster one.  The picture does not depend on it.
-    struct WalkTune {
-        int state = 0;        // 0 warm-up frame, 1 timing "walk to the end", 2 timing "stop early", 3 decided
-        bool pending = false; // walkEv[] of the frame being timed are recorded
-        float msWhole = 0.0f;
-        int choice = 8;       // walkStop in use once decided
-        hipEvent_t ev[2] = {nullptr, nullptr};
-    } walkTune;
-    int tuneMinRays = 4;                             // RT_WF_MIN_RAYS: floor of the rays-per-wave rule
-    int tuneCoopA = 8, tuneCoopB = 12;               // RT_WF_COOP_A / _B: the per-round rule of WfParams::coopA
-    int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 2, tuneChunk = 64, tunePrimaryBlocks = 32, tunePrimaryVia = -1;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
-    int tuneCacheNodes = 896;                        // RT_WF_CACHE_NODES: 28 KB + 12 KB of wave scratch per block, 4 blocks per CU
-
-    DevBuf counters;
-    bool profile = false;
-    std::vector<TimedSpan> spans;
-    std::vector<hipEvent_t> eventPool;
-    double accMs[RT_TIME_KINDS] = {};
-    uint64_t accN[RT_TIME_KINDS] = {};
-};
+#include "rt_context.h"
 
 namespace {
-
-int fail(rt_ctx *c, int code, const std::string &msg) {
-    if (c) c->error = msg;
-    return code;
-}
-
-int hipFail(rt_ctx *c, hipError_t e, const char *what) {
-    return fail(c, e == hipErrorOutOfMemory ? RT_ENOMEM : RT_EHIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-
-#define HIP_TRY(ctx, call)                                      \
-    do {                                                        \
-        hipError_t e_ = (call);                                 \
-        if (e_ != hipSuccess) return hipFail(ctx, e_, #call);   \
-    } while (0)
-
-int bind(rt_ctx *c) {
-    HIP_TRY(c, hipSetDevice(c->device));
-    return RT_OK;
-}
-
-int ensure(rt_ctx *c, DevBuf &b, size_t bytes) {
-    if (bytes == 0) bytes = 16;
-    if (b.p && b.bytes >= bytes) return RT_OK;
-    if (b.p) {
-        HIP_TRY(c, hipFree(b.p));
-        b.p = nullptr;
-        b.bytes = 0;
-    }
-    HIP_TRY(c, hipMalloc(&b.p, bytes));
-    b.bytes = bytes;
-    return RT_OK;
-}
-
-int uploadTo(rt_ctx *c, DevBuf &b, const void *src, size_t bytes) {
-    int r = ensure(c, b, bytes);
-    if (r) return r;
-    if (bytes) {
-        // the caller's buffer is only borrowed for this call: synchronous copy
-        HIP_TRY(c, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    return RT_OK;
-}
-
-void releaseBuf(DevBuf &b) {
-    if (b.p) (void)hipFree(b.p);
-    b.p = nullptr;
-    b.bytes = 0;
-}
-
-hipEvent_t takeEvent(rt_ctx *c) {
-    if (!c->eventPool.empty()) {
-        hipEvent_t e = c->eventPool.back();
-        c->eventPool.pop_back();
-        return e;
-    }
-    hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
-    return e;
-}
 
 // Fold finished spans into the accumulators (blocks until the last recorded one has finished).
 int drainSpans(rt_ctx *c) {
@@ -256,35 +140,6 @@ void rtMarkKernel(void *opaque, int kind, bool begin) {
     }
 }
 
-namespace {
-
-bool rectOk(const rt_ctx *c, const rt_rect &r) {
-    return r.x0 >= 0 && r.y0 >= 0 && r.x1 <= c->width && r.y1 <= c->height && r.x0 <= r.x1 && r.y0 <= r.y1;
-}
-
-rt_rect fullRect(const rt_ctx *c) { return rt_rect{0, 0, c->width, c->height}; }
-
-struct ImageRef {
-    void *p;
-    size_t pixelBytes;
-};
-
-ImageRef imageOf(rt_ctx *c, int image) {
-    switch (image) {
-    case RT_IMAGE_COLOR: return {c->color.p, 16};
-    case RT_IMAGE_NORMAL: return {c->normal.p, 4};
-    case RT_IMAGE_POSITION: return {c->pos.p, 8};
-    case RT_IMAGE_FILTERED: return {c->filteredIndex >= 0 ? c->filt[c->filteredIndex].p : nullptr, 8};
-    case RT_IMAGE_TRIDX: return {c->tridx.p, 4};
-    case RT_IMAGE_VISITS: return {c->visits.p, 4};
-    case RT_IMAGE_STATS: return {c->stats.p, 16};
-    case RT_IMAGE_LDR: return {c->ldr.p, 4};
-    default: return {nullptr, 0};
-    }
-}
-
-} // namespace
-
 extern "C" {
 
 const char *rt_version(void) { return "raytracer_amd gfx950 launcher 0.2 (round 2)"; }
@@ -295,6 +150,11 @@ void rt_work_group_size(int kernel, int out_xyz[3]) {
     out_xyz[0] = 16; // a 256-thread block covers a 16x16 pixel tile (four 8x8 waves)
     out_xyz[1] = 16;
     out_xyz[2] = 1;
+}
+
+int rt_walk_stop(const rt_ctx *c) {
+    if (!c) return 0;
+    return c->lastWalkSettled ? c->lastWalkStop : 0;
 }
 
 size_t rt_image_pixel_bytes(int image) {
@@ -359,6 +219,7 @@ void rt_destroy(rt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    rtCommRelease(c);
     for (TimedSpan &s : c->spans) {
         (void)hipEventDestroy(s.start);
         (void)hipEventDestroy(s.stop);
@@ -398,6 +259,7 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
     case RT_SLOT_NODES: {
         c->walkTune.state = 0;
         c->walkTune.pending = false;
+        c->lastWalkSettled = false;
         if (nbytes % sizeof(RtNode48)) return fail(c, RT_EINVAL, "rt_upload: node stream is not a multiple of 48 bytes");
         const size_t n = nbytes / sizeof(RtNode48);
         if (n == 0 || n > 0x7FFFFFFFu / 2) return fail(c, RT_EINVAL, "rt_upload: node count out of range");
@@ -533,6 +395,8 @@ int rt_resize(rt_ctx *c, int width, int height) {
     int r = bind(c);
     if (r) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rtCommQuiesce(c);
+    if (width != c->width || height != c->height) c->assembledPixelBytes = 0; // the assembled frame belongs to the old size
     const size_t n = (size_t)width * height;
     if ((r = ensure(c, c->color, n * 16)) || (r = ensure(c, c->normal, n * 4)) || (r = ensure(c, c->pos, n * 8)) ||
         (r = ensure(c, c->filt[0], n * 8)) || (r = ensure(c, c->filt[1], n * 8)) || (r = ensure(c, c->tridx, n * 4)) ||
@@ -540,6 +404,7 @@ int rt_resize(rt_ctx *c, int width, int height) {
         return r;
     c->walkTune.state = 0;
     c->walkTune.pending = false;
+    c->lastWalkSettled = false;
     c->width = width;
     c->height = height;
     return rt_clear(c);
@@ -667,7 +532,9 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     wp.walkStop = c->tuneWalkStop > 0 ? c->tuneWalkStop : (beyondL2 ? 3 : 8);
     wp.walkMin = c->tuneWalkMin > 0 ? c->tuneWalkMin : (beyondL2 ? 1 : 40);
     rt_ctx::WalkTune &wt = c->walkTune;
-    const bool tuning = !noAlloc && c->tuneWalkStop == 0 && !beyondL2 && tilePixels * (size_t)n >= ((size_t)1 << 20);
+    // (frames without secondary rays have no extend launches: nothing to compare)
+    const bool tuning = !noAlloc && c->tuneWalkStop == 0 && !beyondL2 && p->maxBounces >= 1 &&
+                        tilePixels * (size_t)n >= ((size_t)1 << 20);
     if (tuning) {
         if (wt.pending) { // the frame timed by the previous call (blocks only during the first three frames)
             float ms = 0.0f;
@@ -684,6 +551,8 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         }
         wp.walkStop = wt.state == 2 ? 1 : wt.state == 3 ? wt.choice : 8;
     }
+    c->lastWalkStop = wp.walkStop;
+    c->lastWalkSettled = !tuning || wt.state == 3;
     wp.extendChunk = c->tuneChunk;
     // full waves test their leaves cooperatively when the triangles do not fit the L2s (measured on MI355X: the
     // coalesced triangle reads of that scheme win on the 1.7 M-triangle lattice, 3.66 -> 3.28 ms, and lose to
@@ -982,9 +851,15 @@ int rt_tonemap(rt_ctx *c, int source_image, float exposure, const rt_rect *tile)
     else if (source_image == RT_IMAGE_FILTERED) {
         if (c->filteredIndex < 0) return fail(c, RT_ESTATE, "rt_tonemap: no filtered image yet");
         f16 = (const uint2 *)c->filt[c->filteredIndex].p;
-    } else return fail(c, RT_EINVAL, "rt_tonemap: source must be RT_IMAGE_COLOR or RT_IMAGE_FILTERED");
+    } else if (source_image == RT_IMAGE_ASSEMBLED) { // the frame rt_gather_tiles put together: RGBA32F or RGBA16F
+        if (!c->assembled.p || (c->assembledPixelBytes != 16 && c->assembledPixelBytes != 8))
+            return fail(c, RT_ESTATE, "rt_tonemap: no assembled colour frame yet");
+        if (c->assembledPixelBytes == 16) f32 = (const float4 *)c->assembled.p;
+        else f16 = (const uint2 *)c->assembled.p;
+    } else return fail(c, RT_EINVAL, "rt_tonemap: source must be RT_IMAGE_COLOR, RT_IMAGE_FILTERED or RT_IMAGE_ASSEMBLED");
     int rc = bind(c);
     if (rc) return rc;
+    if (source_image == RT_IMAGE_ASSEMBLED && (rc = rtCommOrderAfterGather(c))) return rc;
     SpanGuard span(c, TK_TONEMAP);
     hipError_t e = rtLaunchTonemap(f32, f16, (uint32_t *)c->ldr.p, c->width, r, exposure, c->stream);
     span.end();
@@ -1000,6 +875,7 @@ int rt_readback(rt_ctx *c, int image, void *dst, size_t nbytes) {
     if (nbytes != need) return fail(c, RT_EINVAL, "rt_readback: size mismatch, need " + std::to_string(need));
     int rc = bind(c);
     if (rc) return rc;
+    if (image == RT_IMAGE_ASSEMBLED && (rc = rtCommOrderAfterGather(c))) return rc;
     HIP_TRY(c, hipMemcpyAsync(dst, im.p, need, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -1107,6 +983,7 @@ int rt_sync(rt_ctx *c) {
     int rc = bind(c);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    rtCommQuiesce(c);
     return RT_OK;
 }
 

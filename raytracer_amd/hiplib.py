@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librt_hip.so")
 
 (IMAGE_COLOR, IMAGE_NORMAL, IMAGE_POSITION, IMAGE_FILTERED, IMAGE_TRIDX, IMAGE_VISITS, IMAGE_STATS,
- IMAGE_LDR) = range(8)
+ IMAGE_LDR, IMAGE_ASSEMBLED) = range(9)
+COMM_ID_BYTES = 128
 KERNEL_TRACE3, KERNEL_TRACE3_RL, KERNEL_TRACE, KERNEL_TRACE1, KERNEL_TRACE2 = range(5)
 FLAG_AUX, FLAG_PIXEL_STATS, FLAG_NO_COUNTERS, FLAG_PER_PIXEL_KERNEL, FLAG_FAST_SHADOWS, FLAG_WATERTIGHT = 1, 2, 4, 8, 16, 32
 MAX_BATCH = 16
@@ -67,6 +68,7 @@ EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_uplo
            "rt_clear", "rt_trace", "rt_trace_batch", "rt_trace_batch_static", "rt_static_max_paths", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
            "rt_readback_rect_device", "rt_write_rect_device", "rt_write_rect_device_async", "rt_write_image", "rt_image_pixel_bytes",
            "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
+           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_gather_tiles", "rt_walk_stop",
            "rt_work_group_size", "rt_version"]
 
 _lib = None
@@ -111,6 +113,11 @@ def lib():
         L.rt_profile.argtypes = [vp, i32]
         L.rt_timings_read.argtypes = [vp, ctypes.POINTER(Timings), i32]
         L.rt_sync.argtypes = [vp]
+        L.rt_comm_unique_id.argtypes = [vp, sz]
+        L.rt_comm_init.argtypes = [vp, i32, i32, vp, sz]
+        L.rt_comm_destroy.argtypes = [vp]
+        L.rt_gather_tiles.argtypes = [vp, i32, rp, i32, i32]
+        L.rt_walk_stop.argtypes = [vp]
         L.rt_work_group_size.argtypes = [i32, ctypes.POINTER(ctypes.c_int * 3)]
         L.rt_work_group_size.restype = None
         L.rt_version.restype = ctypes.c_char_p
@@ -253,6 +260,44 @@ class Context:
 
     def tonemap(self, source=IMAGE_COLOR, exposure=1.0, rect=None):
         self._check(lib().rt_tonemap(self._h, source, exposure, self._rect(rect)), "rt_tonemap")
+
+    # ---- multi-GPU (rt_comm_* / rt_gather_tiles)
+    @staticmethod
+    def comm_unique_id():
+        """The 128-byte RCCL id rank 0 makes and hands to the other ranks."""
+        buf = (ctypes.c_char * COMM_ID_BYTES)()
+        r = lib().rt_comm_unique_id(buf, COMM_ID_BYTES)
+        if r != 0:
+            raise RtError(f"rt_comm_unique_id failed with {r}: RCCL (librccl.so.1) could not be opened")
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, comm_id=None):
+        """comm_id=None with nranks == 1: local mode (no communicator)."""
+        if comm_id is None:
+            self._check(lib().rt_comm_init(self._h, nranks, rank, None, 0), "rt_comm_init")
+        else:
+            buf = (ctypes.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+            self._check(lib().rt_comm_init(self._h, nranks, rank, buf, COMM_ID_BYTES), "rt_comm_init")
+
+    def comm_destroy(self):
+        self._check(lib().rt_comm_destroy(self._h), "rt_comm_destroy")
+
+    def gather_tiles(self, image, rects, root=0):
+        """Queues the gather of `image`'s per-rank tiles (rects[r] = rank r's tile) into IMAGE_ASSEMBLED on root;
+        returns at once (the streams are ordered by events)."""
+        arr = (Rect * len(rects))(*[Rect(*r) for r in rects])
+        self._check(lib().rt_gather_tiles(self._h, image, arr, len(rects), root), "rt_gather_tiles")
+
+    def readback_assembled(self, image):
+        """The frame rt_gather_tiles last assembled on this (root) rank, in `image`'s pixel format."""
+        dt, ch = _IMAGE_DTYPES[image]
+        shape = (self.height, self.width, ch) if ch > 1 else (self.height, self.width)
+        out = np.empty(shape, dt)
+        self._check(lib().rt_readback(self._h, IMAGE_ASSEMBLED, out.ctypes.data, out.nbytes), "rt_readback(assembled)")
+        return out
+
+    def walk_stop(self):
+        return int(lib().rt_walk_stop(self._h))
 
     def readback(self, image):
         dt, ch = _IMAGE_DTYPES[image]

@@ -4,8 +4,10 @@
 #include <new>
 
 #include "../../include/rt_host.h"
+#include "glfw_setter.hpp"
 #include "png_write.hpp"
 #include "scene.hpp"
+#include "tiling.hpp"
 
 using rtm::vec3;
 
@@ -35,6 +37,45 @@ void rt_update_rays(const vec3 &eye, const vec3 &lookAt, const vec3 &up, float f
 }
 
 extern "C" {
+
+int rth_tile_rect(int width, int height, int world, int rank, int halo, int32_t out_rect[4], int32_t out_grid[2]) {
+    if (width <= 0 || height <= 0 || world <= 0 || rank < 0 || rank >= world || halo < 0 || !out_rect) return -1;
+    const rt_rect r = rttile::tileRect(width, height, world, rank, halo);
+    out_rect[0] = r.x0; out_rect[1] = r.y0; out_rect[2] = r.x1; out_rect[3] = r.y1;
+    if (out_grid) {
+        int gx, gy;
+        rttile::tileGrid(width, height, world, halo, gx, gy);
+        out_grid[0] = gx;
+        out_grid[1] = gy;
+    }
+    return 0;
+}
+
+int rth_input_event(int key, double scroll, float state[11], int32_t ints[4]) {
+    if (!state || !ints) return -1;
+    Camera cam(vec3(state[0], state[1], state[2]), vec3(state[3], state[4], state[5]), vec3(state[6], state[7], state[8]),
+               state[9], 1.0f, 1.0f, 1.0f, 2.0f);
+    int maxBounces = ints[1], iterations = ints[2];
+    GlfwSetter::reset();
+    GlfwSetter::camera = &cam;
+    GlfwSetter::frameNumber = ints[0];
+    GlfwSetter::maxBounces = &maxBounces;
+    GlfwSetter::iterations = &iterations;
+    GlfwSetter::filter = ints[3] != 0;
+    GlfwSetter::exposure = state[10];
+    if (key) GlfwSetter::key_callback(key, 0, GLFW_PRESS, 0);
+    if (scroll != 0.0) GlfwSetter::scroll_callback(0.0, scroll);
+    state[0] = cam.eye.x; state[1] = cam.eye.y; state[2] = cam.eye.z;
+    state[3] = cam.lookAt.x; state[4] = cam.lookAt.y; state[5] = cam.lookAt.z;
+    state[9] = cam.fov;
+    state[10] = GlfwSetter::exposure;
+    ints[0] = GlfwSetter::frameNumber;
+    ints[1] = maxBounces;
+    ints[2] = iterations;
+    ints[3] = GlfwSetter::filter ? 1 : 0;
+    GlfwSetter::reset();
+    return 0;
+}
 
 rth_scene *rth_scene_load_obj(const char *path) {
     if (!path) return nullptr;

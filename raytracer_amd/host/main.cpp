@@ -2,52 +2,263 @@
 // same objects built in the same order, `frames` iterations of trace (+ filter), then PNGs.
 //   rt_headless scene.obj [--size WxH] [--frames N] [--bounces B] [--filter ITERS] [--exposure E]
 //               [--auto-camera] [--light] [--out PREFIX] [--res DIR] [--kernel trace3|trace|trace1|trace2]
+//               [--keys "FRAME:KEY,FRAME:KEY,..."] [--reset-at FRAME] [--freeze-time] [--dump-raw PREFIX] [--gpus N]
 // --kernel selects one of the reference's other kernels (its analytic box scenes; the obj file is still loaded,
 // as the reference's main does, but not traced); trace1 / trace2 read their tables from --res (default "res").
+// --keys feeds the reference's input handler (glfw_setter.hpp) before the given frame of the loop: W A S D Z X move the
+// camera and restart the accumulation, COMMA / PERIOD change maxBounces (restart), SPACE toggles the filter, MINUS /
+// EQUAL change its iterations, 1 / 2 the exposure, SCROLL+n / SCROLL-n the field of view; --reset-at K stands for any
+// input that only resets frameNumber at frame K.  --gpus N renders on N GPUs of this node, one host thread and one
+// launcher context per GPU: the frame is split into screen-space tiles (tiling.hpp), every GPU traces its tile plus the
+// filter halo and filters it locally, rt_gather_tiles assembles the frame on GPU 0 over RCCL.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
+#include <sstream>
 #include <string>
+#include <thread>
+#include <vector>
 
+#include "glfw_setter.hpp"
+#include "png_write.hpp"
 #include "render.hpp"
 #include "rt_loader.hpp"
 #include "scene.hpp"
+#include "tiling.hpp"
+
+namespace {
+
+struct Options {
+    std::string obj;
+    int width = 512, height = 512, frames = 4, bounces = 5, filterIters = 0, gpus = 0;
+    float exposure = 1.0f, time0 = 1.25f, timeStep = 0.0625f;
+    bool autoCamera = false, light = false, freezeTime = false;
+    std::string out = "frame", res = "res", kernel = "trace3", dumpRaw;
+    int launchFlags = 0, maxFollows = 1000, resetAt = -1;
+    std::vector<std::pair<int, std::string>> keys; // (frame, key name)
+};
+
+struct FrameState { // what the loop of reference main.cpp:67-134 sees at the top of one iteration
+    rtm::vec3 eye, lookAt;
+    float fov, exposure;
+    int frameNumber, maxBounces, iterations;
+    bool filterOn;
+};
+
+int keyCode(const std::string &k) {
+    static const std::pair<const char *, int> names[] = {
+        {"W", GLFW_KEY_W}, {"A", GLFW_KEY_A}, {"S", GLFW_KEY_S}, {"D", GLFW_KEY_D}, {"Z", GLFW_KEY_Z}, {"X", GLFW_KEY_X},
+        {"COMMA", GLFW_KEY_COMMA}, {"PERIOD", GLFW_KEY_PERIOD}, {"SPACE", GLFW_KEY_SPACE}, {"MINUS", GLFW_KEY_MINUS},
+        {"EQUAL", GLFW_KEY_EQUAL}, {"1", GLFW_KEY_1}, {"2", GLFW_KEY_2}};
+    for (const auto &n : names)
+        if (k == n.first) return n.second;
+    return -1;
+}
+
+// Dry run of the input script: the per-frame state every GPU replays (the handler's state is process-wide, like the
+// reference's static members, so it is evaluated once, here).
+bool scriptStates(const Options &o, Camera camera, std::vector<FrameState> &states) {
+    GlfwSetter::reset();
+    GlfwSetter::camera = &camera;
+    int maxBounces = o.bounces, iterations = std::max(o.filterIters, 1);
+    GlfwSetter::maxBounces = &maxBounces;
+    GlfwSetter::iterations = &iterations;
+    GlfwSetter::filter = o.filterIters > 0;
+    GlfwSetter::exposure = o.exposure;
+    for (int f = 0; f < o.frames; ++f) {
+        for (const auto &k : o.keys) {
+            if (k.first != f) continue;
+            if (k.second.rfind("SCROLL", 0) == 0) {
+                GlfwSetter::scroll_callback(0.0, std::atof(k.second.c_str() + 6));
+            } else {
+                const int code = keyCode(k.second);
+                if (code < 0) {
+                    std::cerr << "unknown key " << k.second << std::endl;
+                    return false;
+                }
+                GlfwSetter::key_callback(code, 0, GLFW_PRESS, 0);
+            }
+        }
+        if (f == o.resetAt) GlfwSetter::frameNumber = 0;
+        states.push_back(FrameState{camera.eye, camera.lookAt, camera.fov, GlfwSetter::exposure, GlfwSetter::frameNumber,
+                                    maxBounces, iterations, GlfwSetter::filter});
+        GlfwSetter::frameNumber++; // main.cpp:129
+    }
+    GlfwSetter::reset();
+    return true;
+}
+
+bool dumpFile(const std::string &path, const void *p, size_t n) {
+    std::ofstream os(path, std::ios::binary);
+    os.write(static_cast<const char *>(p), (std::streamsize)n);
+    return (bool)os;
+}
+
+struct Shared { // what the GPU threads read (built once) and where they report
+    const Options *o;
+    ModelLoader *loader;
+    QTable *qt;
+    BVHContainer *bvh;
+    Camera camera0;
+    std::vector<FrameState> states;
+    unsigned char commId[RT_COMM_ID_BYTES];
+    std::vector<int> status;
+    std::vector<std::string> errors;
+};
+
+// The body of the reference's main() from the FrameBuffer on (main.cpp:32-134), on one GPU; with nranks > 1 for one
+// tile of the frame.
+void renderOn(Shared &sh, int rank, int nranks) {
+    const Options &o = *sh.o;
+    try {
+        if (nranks > 0) rtMakeContextCurrent(rank); // one context per GPU, current on this thread
+        const RtApi &api = rtApi();
+        rt_ctx *ctx = rtCurrentContext();
+        const int W = o.width, H = o.height;
+        const bool tiled = nranks > 0;
+        const int world = tiled ? nranks : 1;
+        if (tiled) rtCheck(api.comm_init(ctx, world, rank, sh.commId, RT_COMM_ID_BYTES), "rt_comm_init");
+
+        FrameBuffer framebuffer(W, H);
+        Filter filter(W, H, framebuffer.texture, framebuffer.normalTex, framebuffer.posTex);
+        Camera camera = sh.camera0;
+        const std::string main_cs = "src/shaders/" + o.kernel + ".cs";
+        Tracer tracer = o.kernel == "trace3"
+                            ? Tracer(&camera, &framebuffer, sh.bvh, sh.qt)
+                            : Tracer(&camera, &framebuffer, sh.bvh, sh.qt,
+                                     std::vector<const char *>{main_cs.c_str(), "src/shaders/random.glsl"});
+        tracer.resourceDir = o.res;
+        if (o.kernel == "trace1") tracer.genBlueNoiseBuffers();
+        if (o.kernel == "trace2") tracer.genLtcData();
+        tracer.launchFlags = o.launchFlags;
+        tracer.maxFollows = o.maxFollows;
+        rtCheck(api.profile(ctx, 1), "rt_profile");
+
+        bool filtered = false;
+        float exposure = o.exposure;
+        for (int f = 0; f < o.frames; ++f) { // the loop of main.cpp:67-134
+            const FrameState &s = sh.states[f];
+            camera.eye = s.eye;
+            camera.lookAt = s.lookAt;
+            camera.fov = s.fov;
+            tracer.maxBounces = s.maxBounces;
+            filter.iterations = s.iterations;
+            exposure = s.exposure;
+            filtered = s.filterOn;
+            const int halo = filtered ? rttile::filterHalo(s.iterations) : 0;
+            std::vector<rt_rect> rects((size_t)world);
+            for (int r = 0; r < world; ++r) rects[(size_t)r] = rttile::tileRect(W, H, world, r, halo);
+            if (tiled) {
+                tracer.tile = rttile::growRect(rects[(size_t)rank], halo, W, H);
+                filter.tile = rects[(size_t)rank];
+            }
+            tracer.timeOverride = o.time0 + o.timeStep * (float)f;
+            tracer.freezeTime = o.freezeTime && f > 0;
+            tracer.trace(s.frameNumber);
+            if (filtered) {
+                filter.filter();
+                filter.setTextureRead();
+            } else {
+                framebuffer.setTextureRead();
+            }
+            if (tiled)
+                rtCheck(api.gather_tiles(ctx, (int)FrameBuffer::readTexture, rects.data(), world, 0), "rt_gather_tiles");
+        }
+        rtCheck(api.sync(ctx), "rt_sync");
+
+        if (rank == 0) {
+            const unsigned shown = tiled ? (unsigned)RT_IMAGE_ASSEMBLED : (filtered ? (unsigned)RT_IMAGE_FILTERED : (unsigned)RT_IMAGE_COLOR);
+            if (!tiled) framebuffer.saveToImage(o.out + "_linear.png");
+            framebuffer.saveTonemapped(o.out + ".png", shown, exposure);
+            if (!o.dumpRaw.empty()) {
+                const size_t n = (size_t)W * H;
+                std::vector<unsigned char> buf(n * 16);
+                auto dump = [&](int image, size_t pb, const char *suffix) {
+                    rtCheck(api.readback(ctx, image, buf.data(), n * pb), "rt_readback");
+                    if (!dumpFile(o.dumpRaw + suffix, buf.data(), n * pb)) std::cerr << "ERROR::FILE::COULD NOT WRITE " << o.dumpRaw << suffix << std::endl;
+                };
+                if (tiled) {
+                    dump(RT_IMAGE_ASSEMBLED, filtered ? 8 : 16, filtered ? "_assembled.f16" : "_assembled.f32");
+                } else {
+                    dump(RT_IMAGE_COLOR, 16, "_color.f32");
+                    dump(RT_IMAGE_NORMAL, 4, "_normal.i8");
+                    dump(RT_IMAGE_POSITION, 8, "_pos.f16");
+                    if (filtered) dump(RT_IMAGE_FILTERED, 8, "_filtered.f16");
+                }
+            }
+        }
+        rt_timings t;
+        rtCheck(api.timings_read(ctx, &t, 0), "rt_timings_read");
+        const rt_counters c = tracer.counters();
+        std::ostringstream line;
+        line.setf(std::ios::fixed);
+        line.precision(3);
+        line << (tiled ? "gpu " + std::to_string(rank) + ": " : std::string()) << W << " x " << H << ", " << o.frames
+             << " frames, " << o.bounces << " bounces: trace " << t.ms[RT_TIME_TRACE] << " ms, filter " << t.ms[RT_TIME_FILTER]
+             << " ms (" << t.launches[RT_TIME_FILTER] << " passes); " << c.rays << " rays, "
+             << (t.ms[RT_TIME_TRACE] > 0 ? c.rays / (t.ms[RT_TIME_TRACE] * 1e3) : 0.0) << " Mrays/s\n";
+        std::cout << line.str() << std::flush;
+        rtReleaseCurrentContext();
+        sh.status[(size_t)rank] = 0;
+    } catch (const std::exception &e) {
+        sh.errors[(size_t)rank] = e.what();
+        sh.status[(size_t)rank] = 1;
+    }
+}
+
+} // namespace
 
 int main(int argc, char **argv) {
     if (argc < 2) {
         std::cout << "Usage:\t" << argv[0] << "\tobj_file_path [options]" << std::endl;
         return -1;
     }
-    int WIDTH = 512, HEIGHT = 512, frames = 4, bounces = 5, filterIters = 0;
-    float exposure = 1.0f;
-    bool autoCamera = false, light = false;
-    std::string out = "frame", res = "res", kernel = "trace3";
-    int launchFlags = 0, maxFollows = 1000;
+    Options o;
+    o.obj = argv[1];
     for (int i = 2; i < argc; ++i) {
         const std::string a = argv[i];
         auto next = [&]() -> const char * { return i + 1 < argc ? argv[++i] : ""; };
-        if (a == "--size") std::sscanf(next(), "%dx%d", &WIDTH, &HEIGHT);
-        else if (a == "--frames") frames = std::atoi(next());
-        else if (a == "--bounces") bounces = std::atoi(next());
-        else if (a == "--filter") filterIters = std::atoi(next());
-        else if (a == "--exposure") exposure = (float)std::atof(next());
-        else if (a == "--auto-camera") autoCamera = true;
-        else if (a == "--light") light = true;
-        else if (a == "--out") out = next();
-        else if (a == "--res") res = next();
-        else if (a == "--kernel") kernel = next();
-        else if (a == "--watertight") launchFlags |= RT_FLAG_WATERTIGHT;      // opt-in variants, not the reference's algorithm
-        else if (a == "--fast-shadows") launchFlags |= RT_FLAG_FAST_SHADOWS;
-        else if (a == "--max-follows") maxFollows = std::atoi(next());
-        else { std::cerr << "unknown option " << a << std::endl; return -1; }
+        if (a == "--size") std::sscanf(next(), "%dx%d", &o.width, &o.height);
+        else if (a == "--frames") o.frames = std::atoi(next());
+        else if (a == "--bounces") o.bounces = std::atoi(next());
+        else if (a == "--filter") o.filterIters = std::atoi(next());
+        else if (a == "--exposure") o.exposure = (float)std::atof(next());
+        else if (a == "--auto-camera") o.autoCamera = true;
+        else if (a == "--light") o.light = true;
+        else if (a == "--out") o.out = next();
+        else if (a == "--res") o.res = next();
+        else if (a == "--kernel") o.kernel = next();
+        else if (a == "--watertight") o.launchFlags |= RT_FLAG_WATERTIGHT;      // opt-in variants, not the reference's algorithm
+        else if (a == "--fast-shadows") o.launchFlags |= RT_FLAG_FAST_SHADOWS;
+        else if (a == "--max-follows") o.maxFollows = std::atoi(next());
+        else if (a == "--reset-at") o.resetAt = std::atoi(next());
+        else if (a == "--freeze-time") o.freezeTime = true;
+        else if (a == "--dump-raw") o.dumpRaw = next();
+        else if (a == "--gpus") o.gpus = std::atoi(next());
+        else if (a == "--time0") o.time0 = (float)std::atof(next());
+        else if (a == "--keys") {
+            std::stringstream ss(next());
+            std::string item;
+            while (std::getline(ss, item, ',')) {
+                const size_t c = item.find(':');
+                if (c == std::string::npos) { std::cerr << "--keys wants FRAME:KEY items" << std::endl; return -1; }
+                o.keys.emplace_back(std::atoi(item.substr(0, c).c_str()), item.substr(c + 1));
+            }
+        } else { std::cerr << "unknown option " << a << std::endl; return -1; }
+    }
+    if (o.kernel != "trace3" && o.kernel != "trace" && o.kernel != "trace1" && o.kernel != "trace2") {
+        std::cerr << "unknown kernel " << o.kernel << std::endl;
+        return -1;
+    }
+    if (o.gpus < 0 || o.gpus > 64 || o.frames < 1 || o.width < 1 || o.height < 1) {
+        std::cerr << "bad --gpus / --frames / --size" << std::endl;
+        return -1;
     }
     try {
-        FrameBuffer framebuffer(WIDTH, HEIGHT);
-        Filter filter(WIDTH, HEIGHT, framebuffer.texture, framebuffer.normalTex, framebuffer.posTex);
-
-        ModelLoader loader(argv[1]);
+        ModelLoader loader(o.obj.c_str());
         if (loader.triangles.empty()) {
             std::cerr << "ERROR::FILE::NO TRIANGLES LOADED" << std::endl;
             return -1;
@@ -56,7 +267,7 @@ int main(int argc, char **argv) {
         loader.bounds(lo, hi);
         const rtm::vec3 d = hi - lo;
         const float diag = std::sqrt(d.x * d.x + d.y * d.y + d.z * d.z);
-        if (light && loader.emitters.empty())
+        if (o.light && loader.emitters.empty())
             loader.addQuadLight(rtm::vec3((lo.x + hi.x) * 0.5f, hi.y + 0.1f * diag, (lo.z + hi.z) * 0.5f),
                                 0.25f * d.x, 0.25f * d.z, rtm::vec3(0.553949f, 0.914877f, 1.0f));
         QTable qt(loader.numObjs);
@@ -65,53 +276,34 @@ int main(int argc, char **argv) {
                          qt.voronoi_centres);
 
         rtm::vec3 eye(0.0f, 2.2f, 3.5f), lookAt(0.0f, 3.0f, 0.0f);
-        if (autoCamera) {
+        if (o.autoCamera) {
             lookAt = (lo + hi) * 0.5f;
             eye = lookAt + rtm::vec3(0.3f, 0.4f, 1.0f) * (1.5f * diag);
         }
-        Camera camera(eye, lookAt, rtm::vec3(0.0f, 1.0f, 0.0f), 60.0f, (float)WIDTH, (float)HEIGHT, 1.0f, 2.0f);
-
-        const std::string main_cs = "src/shaders/" + kernel + ".cs";
-        if (kernel != "trace3" && kernel != "trace" && kernel != "trace1" && kernel != "trace2") {
-            std::cerr << "unknown kernel " << kernel << std::endl;
-            return -1;
-        }
-        Tracer tracer = kernel == "trace3"
-                            ? Tracer(&camera, &framebuffer, &bvh, &qt)
-                            : Tracer(&camera, &framebuffer, &bvh, &qt,
-                                     std::vector<const char *>{main_cs.c_str(), "src/shaders/random.glsl"});
-        tracer.resourceDir = res;
-        if (kernel == "trace1") tracer.genBlueNoiseBuffers();
-        if (kernel == "trace2") tracer.genLtcData();
-        tracer.maxBounces = bounces;
-        tracer.launchFlags = launchFlags;
-        tracer.maxFollows = maxFollows;
-        filter.iterations = filterIters;
-        rtCheck(rtApi().profile(rtCurrentContext(), 1), "rt_profile");
-
-        for (int frameNumber = 0; frameNumber < frames; ++frameNumber) {
-            tracer.timeOverride = 1.25f + 0.0625f * (float)frameNumber;
-            tracer.trace(frameNumber);
-        }
-        if (filterIters > 0) {
-            filter.filter();
-            filter.setTextureRead();
+        Shared sh{&o, &loader, &qt, &bvh,
+                  Camera(eye, lookAt, rtm::vec3(0.0f, 1.0f, 0.0f), 60.0f, (float)o.width, (float)o.height, 1.0f, 2.0f),
+                  {}, {}, {}, {}};
+        if (!scriptStates(o, sh.camera0, sh.states)) return -1;
+        const int threads = std::max(o.gpus, 1);
+        sh.status.assign((size_t)threads, 1);
+        sh.errors.assign((size_t)threads, std::string());
+        if (o.gpus > 0) {
+            rtCheck(rtApi().comm_unique_id(sh.commId, RT_COMM_ID_BYTES), "rt_comm_unique_id");
+            std::vector<std::thread> pool;
+            for (int r = 0; r < o.gpus; ++r) pool.emplace_back(renderOn, std::ref(sh), r, o.gpus);
+            for (std::thread &t : pool) t.join();
         } else {
-            framebuffer.setTextureRead();
+            renderOn(sh, 0, 0);
         }
-        framebuffer.saveToImage(out + "_linear.png");
-        framebuffer.saveTonemapped(out + ".png", FrameBuffer::readTexture, exposure);
-
-        rt_timings t;
-        rtCheck(rtApi().timings_read(rtCurrentContext(), &t, 0), "rt_timings_read");
-        const rt_counters c = tracer.counters();
-        std::printf("%d x %d, %d frames, %d bounces: trace %.3f ms, filter %.3f ms (%d passes); %llu rays, %.1f Mrays/s\n",
-                    WIDTH, HEIGHT, frames, bounces, t.ms[RT_TIME_TRACE], t.ms[RT_TIME_FILTER], (int)t.launches[RT_TIME_FILTER],
-                    (unsigned long long)c.rays, t.ms[RT_TIME_TRACE] > 0 ? c.rays / (t.ms[RT_TIME_TRACE] * 1e3) : 0.0);
-        rtReleaseCurrentContext();
+        int rc = 0;
+        for (int r = 0; r < threads; ++r)
+            if (sh.status[(size_t)r]) {
+                std::cerr << "gpu " << r << ": " << sh.errors[(size_t)r] << std::endl;
+                rc = 1;
+            }
+        return rc;
     } catch (const std::exception &e) {
         std::cerr << e.what() << std::endl;
         return 1;
     }
-    return 0;
 }

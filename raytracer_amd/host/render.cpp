@@ -198,6 +198,7 @@ void Tracer::updateRays() { // Tracer.cpp:110-130
 }
 
 void Tracer::trace(int frameNumber) { // Tracer.cpp:132-198
+    if (!accumulateSamples && frameNumber > maxAccumulateSamples) return; // Tracer.cpp:134-135 (commented out there)
     auto end = std::chrono::system_clock::now();
     std::chrono::duration<double> elapsed_seconds = end - start;
     updateRays();
@@ -207,7 +208,8 @@ void Tracer::trace(int frameNumber) { // Tracer.cpp:132-198
     compute.setVec3("ray10", vec3(ray10.x, ray10.y, ray10.z));
     compute.setVec3("ray11", vec3(ray11.x, ray11.y, ray11.z));
     compute.setVec3("eye", camera->eye);
-    compute.setFloat("time", std::isnan(timeOverride) ? (float)elapsed_seconds.count() : timeOverride);
+    if (!freezeTime) lastTime = std::isnan(timeOverride) ? (float)elapsed_seconds.count() : timeOverride;
+    compute.setFloat("time", lastTime);
     compute.setFloat("blendFactor", (float)frameNumber / (frameNumber + 1.0f));
     compute.setInt("importanceSampled", int(importanceSampled));
     compute.setInt("numPoints", MAX_POINTS);
@@ -225,7 +227,7 @@ void Tracer::trace(int frameNumber) { // Tracer.cpp:132-198
     p.flags = launchFlags;
     p.maxFollows = maxFollows;
     // image / buffer bindings of Tracer.cpp:165-180 are implicit in the context; the dispatch:
-    rtCheck(rtApi().trace(rtCurrentContext(), &p, nullptr), "rt_trace");
+    rtCheck(rtApi().trace(rtCurrentContext(), &p, tile.x1 > tile.x0 ? &tile : nullptr), "rt_trace");
 }
 
 rt_counters Tracer::counters() {
@@ -248,7 +250,8 @@ Filter::Filter(unsigned width, unsigned height, unsigned inputTex, unsigned norm
 }
 
 void Filter::filter() { // filter.cpp:68-104
-    rtCheck(rtApi().filter(rtCurrentContext(), iterations, c_phi0, n_phi0, p_phi0, nullptr), "rt_filter");
+    rtCheck(rtApi().filter(rtCurrentContext(), iterations, c_phi0, n_phi0, p_phi0, tile.x1 > tile.x0 ? &tile : nullptr),
+            "rt_filter");
     readFrom = iterations > 0 ? RT_IMAGE_FILTERED : (int)inputTex;
 }
 

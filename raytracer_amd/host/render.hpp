@@ -99,6 +99,12 @@ public:
 
     bool importanceSampled;
     bool useBlueNoise;
+    // The three tunables reference src/main.cpp:57-59 hands to its input handler.  In the reference they are inert
+    // (the guard of Tracer.cpp:134-135 and the key bindings of glfw_setter.cpp:187-206 are commented out, freezeTime is
+    // never read); here they do what those commented-out lines describe, which at their default values is nothing:
+    //   !accumulateSamples: trace() returns without dispatching once frameNumber > maxAccumulateSamples (Tracer.cpp:134);
+    //   freezeTime: the `time` uniform keeps the value it had when the flag was set, so every frame draws the same
+    //   random numbers (with blendFactor n/(n+1) the accumulated image then stays the first sample).
     bool freezeTime = false;
     bool accumulateSamples;
     int maxAccumulateSamples;
@@ -113,8 +119,13 @@ public:
     // (e.g. RT_FLAG_WATERTIGHT, RT_FLAG_FAST_SHADOWS: opt-in variants that are not the reference's algorithm);
     // maxFollows: MAX_FOLLOWS of trace3.cs:214, to be lifted for scenes of millions of triangles.
     int launchFlags = 0, maxFollows = 1000;
+    // Not in the reference (single GPU): the part of the image this context traces; x1 <= x0 means the whole image.
+    rt_rect tile = {0, 0, 0, 0};
     std::string resourceDir = "res"; // where the sample tables / LUTs are read from
     rt_counters counters();
+
+private:
+    float lastTime = 0.0f; // the `time` of the last dispatch (what freezeTime freezes)
 };
 
 class Filter {
@@ -126,6 +137,8 @@ public:
     int iterations;
     int readFrom;
     float c_phi0, n_phi0, p_phi0;
+    // Not in the reference (single GPU): the part of the image that must be final after filter(); x1 <= x0 = all of it.
+    rt_rect tile = {0, 0, 0, 0};
 
     Filter(unsigned width, unsigned height, unsigned inputTex, unsigned normTex, unsigned posTex);
     void createTextureAttachments(int width, int height) { (void)width; (void)height; }

@@ -13,7 +13,8 @@ namespace {
 
 RtApi g_api;
 bool g_loaded = false;
-rt_ctx *g_ctx = nullptr;
+rt_ctx *g_ctx = nullptr;            // process-wide default context
+thread_local rt_ctx *t_ctx = nullptr; // this thread's own context (rtMakeContextCurrent)
 std::mutex g_mutex;
 
 std::string hostLibraryDir() {
@@ -55,6 +56,7 @@ const RtApi &rtApi() {
     bindSym(lib, "rt_resize", g_api.resize);
     bindSym(lib, "rt_clear", g_api.clear);
     bindSym(lib, "rt_trace", g_api.trace);
+    bindSym(lib, "rt_trace_batch", g_api.trace_batch);
     bindSym(lib, "rt_filter", g_api.filter);
     bindSym(lib, "rt_tonemap", g_api.tonemap);
     bindSym(lib, "rt_readback", g_api.readback);
@@ -64,29 +66,54 @@ const RtApi &rtApi() {
     bindSym(lib, "rt_timings_read", g_api.timings_read);
     bindSym(lib, "rt_sync", g_api.sync);
     bindSym(lib, "rt_work_group_size", g_api.work_group_size);
+    bindSym(lib, "rt_comm_unique_id", g_api.comm_unique_id);
+    bindSym(lib, "rt_comm_init", g_api.comm_init);
+    bindSym(lib, "rt_comm_destroy", g_api.comm_destroy);
+    bindSym(lib, "rt_gather_tiles", g_api.gather_tiles);
+    bindSym(lib, "rt_walk_stop", g_api.walk_stop);
     g_loaded = true;
     return g_api;
 }
 
+static rt_ctx *createOn(const RtApi &api, int dev) {
+    rt_ctx *c = nullptr;
+    const int rc = api.create(dev, &c);
+    if (rc != 0 || !c) {
+        const std::string msg = "ERROR::RT::NO USABLE GPU (rt_create(" + std::to_string(dev) + ") = " +
+                                std::to_string(rc) + "); there is no CPU fallback";
+        std::cerr << msg << std::endl;
+        throw std::runtime_error(msg);
+    }
+    return c;
+}
+
+rt_ctx *rtMakeContextCurrent(int device) {
+    const RtApi &api = rtApi();
+    if (t_ctx) api.destroy(t_ctx);
+    t_ctx = nullptr;
+    t_ctx = createOn(api, device);
+    return t_ctx;
+}
+
 rt_ctx *rtCurrentContext() {
     const RtApi &api = rtApi();
+    if (t_ctx) return t_ctx;
     std::lock_guard<std::mutex> lock(g_mutex);
     if (!g_ctx) {
         const char *d = std::getenv("RT_DEVICE");
         if (!d) d = std::getenv("LOCAL_RANK");
         const int dev = d ? std::atoi(d) : 0;
-        const int rc = api.create(dev, &g_ctx);
-        if (rc != 0 || !g_ctx) {
-            const std::string msg = "ERROR::RT::NO USABLE GPU (rt_create(" + std::to_string(dev) + ") = " +
-                                    std::to_string(rc) + "); there is no CPU fallback";
-            std::cerr << msg << std::endl;
-            throw std::runtime_error(msg);
-        }
+        g_ctx = createOn(api, dev);
     }
     return g_ctx;
 }
 
 void rtReleaseCurrentContext() {
+    if (t_ctx) {
+        if (g_loaded) g_api.destroy(t_ctx);
+        t_ctx = nullptr;
+        return;
+    }
     std::lock_guard<std::mutex> lock(g_mutex);
     if (g_ctx && g_loaded) g_api.destroy(g_ctx);
     g_ctx = nullptr;
@@ -95,7 +122,8 @@ void rtReleaseCurrentContext() {
 void rtCheck(int rc, const char *what) {
     if (rc == 0) return;
     std::string msg = std::string("ERROR::RT::") + what + " failed (" + std::to_string(rc) + ")";
-    if (g_ctx && g_loaded) msg += std::string(": ") + g_api.last_error(g_ctx);
+    rt_ctx *cur = t_ctx ? t_ctx : g_ctx;
+    if (cur && g_loaded) msg += std::string(": ") + g_api.last_error(cur);
     std::cerr << msg << std::endl;
     throw std::runtime_error(msg);
 }

@@ -60,6 +60,9 @@ def lib():
         L.rth_camera_rays.argtypes = [fp, fp, fp] + [ctypes.c_float] * 5 + [fp]
         L.rth_write_png.argtypes = [cp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int]
         L.rth_version.restype = cp
+        L.rth_tile_rect.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int32 * 4), ctypes.POINTER(ctypes.c_int32 * 2)]
+        L.rth_input_event.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_float * 11),
+                                      ctypes.POINTER(ctypes.c_int32 * 4)]
         _lib = L
     return _lib
 
@@ -199,3 +202,25 @@ def write_png(path, rgba8, flip=True):
     r = lib().rth_write_png(os.fsencode(path), w, h, a.ctypes.data, int(flip))
     if r < 0:
         raise RuntimeError(f"rth_write_png: {r}")
+
+
+def tile_rect(width, height, world, rank, halo):
+    """The C++ host's tiling rule (raytracer_amd/host/tiling.hpp): ((x0, y0, x1, y1), (columns, rows))."""
+    r, g = (ctypes.c_int32 * 4)(), (ctypes.c_int32 * 2)()
+    if lib().rth_tile_rect(width, height, world, rank, halo, ctypes.byref(r), ctypes.byref(g)) != 0:
+        raise RuntimeError("rth_tile_rect")
+    return tuple(r), tuple(g)
+
+
+KEYS = dict(W=87, A=65, S=83, D=68, Z=90, X=88, COMMA=44, PERIOD=46, SPACE=32, MINUS=45, EQUAL=61, K1=49, K2=50)
+
+
+def input_event(camera, frame_number, max_bounces, iterations, filter_on, exposure=1.0, key=0, scroll=0.0):
+    """One scripted event through the reference's input-handler state machine (glfw_setter.cpp:77-237,304-310).
+    camera: dict(eye, look_at, up, fov).  Returns (camera, frame_number, max_bounces, iterations, filter_on, exposure)."""
+    st = (ctypes.c_float * 11)(*camera["eye"], *camera["look_at"], *camera["up"], camera["fov"], exposure)
+    it = (ctypes.c_int32 * 4)(frame_number, max_bounces, iterations, int(filter_on))
+    if lib().rth_input_event(int(key), float(scroll), ctypes.byref(st), ctypes.byref(it)) != 0:
+        raise RuntimeError("rth_input_event")
+    cam = dict(eye=tuple(st[0:3]), look_at=tuple(st[3:6]), up=tuple(st[6:9]), fov=float(st[9]))
+    return cam, int(it[0]), int(it[1]), int(it[2]), bool(it[3]), float(st[10])

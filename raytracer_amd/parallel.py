@@ -1,25 +1,29 @@
 """Screen-space tiling of one frame over the GPUs of a node.
 
-One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on CPU).
-The scene, BVH and tables are replicated; rank r owns one tile of a columns x rows grid of the image
-(tile_grid: the grid whose tiles, grown by the filter halo, are smallest: 2 x 1, 2 x 2, 4 x 2 at 16:9).
-Pixels are independent in the trace kernel and its random numbers depend only on the absolute pixel
-position and the frame, so a tile is bit-identical to the same pixels of a single-GPU frame.  The
-à-trous filter needs neighbours: every rank also traces a halo of rt_filter_halo(iterations) pixels
-around its tile (1+3+7+15+31 = 57 for 5 passes) and then filters locally with no communication;
-beyond the true image edge the taps read zero, exactly as on one GPU.  The only collective is ONE
-gather of the finished tiles to rank 0 (tiles padded to equal size; each peer sends over its own
-xGMI link, no ring).
+One process per GPU.  The scene, BVH and tables are replicated; rank r owns one tile of a columns x rows grid of the
+image (tile_grid: the grid whose tiles, grown by the filter halo, are smallest: 2 x 1, 2 x 2, 4 x 2 at 16:9).
+Pixels are independent in the trace kernel and its random numbers depend only on the absolute pixel position and the
+frame, so a tile is bit-identical to the same pixels of a single-GPU frame.  The à-trous filter needs neighbours:
+every rank also traces a halo of rt_filter_halo(iterations) pixels around its tile (1+3+7+15+31 = 57 for 5 passes)
+and then filters locally with no communication; beyond the true image edge the taps read zero, exactly as on one GPU.
+The only exchange is ONE gather of the finished tiles to rank 0.
+
+Product path (HipBackend): the gather is the launcher's own rt_gather_tiles (raytracer_amd/csrc/rt_comm.hip) — RCCL
+ncclSend / ncclRecv in one group, every peer over its own xGMI link, on a second HIP stream ordered with the trace
+stream by events: no host wait, staging allocated once and double-buffered, so gather(k) overlaps trace(k+1).
+torch.distributed is used for the rendezvous only (handing rank 0's RCCL id to the others) and for the benchmark's
+barriers.  The assembled frame is IMAGE_ASSEMBLED of rank 0's context.
+
+Generic path (any other backend: the CPU tests drive this code with a checker backend over gloo; the one-GPU
+rehearsal of bench.py moves GPU tiles through host memory the same way): torch.distributed.gather of padded tiles,
+blocking, assembled into a host array on rank 0.
 
 The renderer behind a tile is a `backend` object (duck-typed):
     backend.trace(rect, frame)            trace all samples of one frame over rect (x0,y0,x1,y1)
     backend.filter(rect)                  filter so that `rect` is final
-    backend.read_rect(image, rect)  -> torch tensor [rows, cols*pixel_bytes] uint8 on the backend's device
-    backend.write_rect(image, rect, tensor)
-    backend.device                        torch device of those tensors
+    backend.read_rect(image, rect)  -> torch uint8 tensor [rows, cols*pixel_bytes] (generic path only)
     backend.halo                          filter halo in pixels (0 when not filtering)
-`HipBackend` below is the product backend (librt_hip.so through hiplib).  Tests drive the same
-code on CPU with a backend of their own.
+    backend.native_gather(image, rects) / backend.native_result(image)    optional: the product path
 """
 import numpy as np
 
@@ -71,6 +75,7 @@ class HipBackend:
         self.max_follows = max_follows  # MAX_FOLLOWS of trace3.cs:214; lifted for scenes of millions of triangles
         self.device = torch_device
         self.halo = hiplib.lib().rt_filter_halo(filter_iters) if filter_iters > 0 else 0
+        self.comm_ready = False
 
     def trace(self, rect, frame=0):
         self.ctx.trace_samples(self.wl.rays, self.wl.eye, spp=self.spp, frame0=frame * self.spp,
@@ -82,6 +87,7 @@ class HipBackend:
             self.ctx.filter(self.filter_iters, rect=rect)
 
     def read_rect(self, image, rect):
+        """Generic path only (bench.py's one-GPU rehearsal over gloo): the tile as a device tensor."""
         import torch
         rows, cols = rect[3] - rect[1], rect[2] - rect[0]
         pb = hiplib.lib().rt_image_pixel_bytes(image)
@@ -90,12 +96,28 @@ class HipBackend:
             self.ctx.readback_rect_device(image, rect, t.data_ptr(), t.numel())
         return t
 
-    def write_rect(self, image, rect, tensor, wait=True):
-        """wait=False only queues the copy on the context's stream: the caller keeps `tensor` alive and unchanged
-        until the context has been synchronised (TiledFrame.gather does)."""
-        if tensor.numel():
-            assert wait or tensor.is_contiguous()
-            self.ctx.write_rect_device(image, rect, tensor.contiguous().data_ptr(), tensor.numel(), wait=wait)
+    # ---- product path: the launcher's own gather
+    def init_comm(self, rank, world, dist=None):
+        """Rendezvous: rank 0 makes the RCCL id, torch.distributed hands it to the others, every rank joins."""
+        if world == 1:
+            self.ctx.comm_init(1, 0, None)
+        else:
+            import torch
+            ident = torch.zeros(hiplib.COMM_ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                ident = torch.frombuffer(bytearray(hiplib.Context.comm_unique_id()), dtype=torch.uint8).clone()
+            on_gpu = dist.get_backend() == "nccl"
+            if on_gpu:
+                ident = ident.to(self.device)
+            dist.broadcast(ident, src=0)
+            self.ctx.comm_init(world, rank, bytes(ident.cpu().numpy().tobytes()))
+        self.comm_ready = True
+
+    def native_gather(self, image, rects):
+        self.ctx.gather_tiles(image, rects, root=0)
+
+    def native_result(self, image):
+        return self.ctx.readback_assembled(image)
 
 
 class TiledFrame:
@@ -105,11 +127,13 @@ class TiledFrame:
         self.b, self.width, self.height, self.rank, self.world = backend, width, height, rank, world
         self.result_image = result_image
         self.grid = tile_grid(width, height, world, backend.halo)
-        self.tile = self.strip = tile_rect(width, height, world, rank, backend.halo)  # (`strip`: the name of the 1-D days)
+        self.rects = [tile_rect(width, height, world, r, backend.halo) for r in range(world)]
+        self.tile = self.rects[rank]
         self.traced = grow_rect(self.tile, backend.halo, width, height)
         self.max_cols, self.max_rows = -(-width // self.grid[0]), -(-height // self.grid[1])
+        self.native = bool(getattr(backend, "comm_ready", False))
         self._pad = self._recv = None
-        self._pasting = []
+        self.assembled = None  # generic path, rank 0: uint8 array [height, width * pixel_bytes]
 
     def render(self, frame=0):
         """Trace tile + halo, filter the tile.  No communication."""
@@ -117,42 +141,38 @@ class TiledFrame:
         self.b.filter(self.tile)
 
     def gather(self, dist=None):
-        """ONE gather of the finished tiles to rank 0, which pastes them into its own image.
-        Returns the padded tile tensor list on rank 0 (None elsewhere)."""
+        """ONE gather of the finished tiles to rank 0.  Product path: queued on the GPU, returns at once."""
+        if self.native:
+            self.b.native_gather(self.result_image, self.rects)
+            return
         if self.world == 1:
-            return None
+            return
         import torch
         if dist is None:
             import torch.distributed as dist
         mine = self.b.read_rect(self.result_image, self.tile)
-        via_host = mine.is_cuda and dist.get_backend() == "gloo"  # rehearsal on a one-GPU box (bench.py)
-        if via_host:
+        if mine.is_cuda:  # rehearsal on a one-GPU box: tiles travel through host memory (blocking copy)
             mine = mine.cpu()
         pb = mine.shape[1] // max(self.tile[2] - self.tile[0], 1)  # bytes per pixel
-        if self._pad is None or self._pad.shape[1] != self.max_cols * pb or self._pad.device != mine.device:
+        if self._pad is None or self._pad.shape[1] != self.max_cols * pb:
             # staging memory is allocated once: every frame re-uses it (what lies beyond a smaller tile stays zero)
-            self._pad = torch.zeros((self.max_rows, self.max_cols * pb), dtype=torch.uint8, device=mine.device)
+            self._pad = torch.zeros((self.max_rows, self.max_cols * pb), dtype=torch.uint8)
             self._recv = [torch.empty_like(self._pad) for _ in range(self.world)] if self.rank == 0 else None
-        pad, recv = self._pad, self._recv
-        pad[: mine.shape[0], : mine.shape[1]] = mine
-        dist.gather(pad, recv, dst=0)
-        if pad.is_cuda:
-            # the launcher copies on its own HIP stream: the collective (and the staging copy above) must have
-            # finished before rank 0 pastes the strips, and before the next frame re-uses the staging memory
-            torch.cuda.current_stream(pad.device).synchronize()
+        self._pad[: mine.shape[0], : mine.shape[1]] = mine
+        dist.gather(self._pad, self._recv, dst=0)  # gloo: blocking, complete on return
         if self.rank == 0:
-            # the peers' tiles are pasted with queued copies (one stream, no host round trip per tile); the tensors
-            # they read are kept until the next gather, whose read_rect synchronises the stream first
-            queued = isinstance(self.b, HipBackend)
-            self._pasting = []
-            for r in range(1, self.world):
-                x0, y0, x1, y1 = tile_rect(self.width, self.height, self.world, r, self.b.halo)
-                part = recv[r][: y1 - y0, : (x1 - x0) * pb].contiguous()
-                if via_host:
-                    part = part.to(self.b.device)
-                self._pasting.append(part)
-                if queued:
-                    self.b.write_rect(self.result_image, (x0, y0, x1, y1), part, wait=False)
-                else:
-                    self.b.write_rect(self.result_image, (x0, y0, x1, y1), part)
-        return recv
+            if self.assembled is None or self.assembled.shape != (self.height, self.width * pb):
+                self.assembled = np.zeros((self.height, self.width * pb), np.uint8)
+            for r, (x0, y0, x1, y1) in enumerate(self.rects):
+                self.assembled[y0:y1, x0 * pb:x1 * pb] = self._recv[r][: y1 - y0, : (x1 - x0) * pb].numpy()
+
+    def result(self):
+        """Rank 0: the assembled frame as a [height, width, channels] array of the result image's dtype (blocking)."""
+        if self.native:
+            return self.b.native_result(self.result_image)
+        dt, ch = hiplib._IMAGE_DTYPES[self.result_image]
+        if self.world == 1:
+            a = self.b.read_rect(self.result_image, (0, 0, self.width, self.height))
+            a = a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)
+            return np.ascontiguousarray(a).view(dt).reshape(self.height, self.width, ch)
+        return np.ascontiguousarray(self.assembled).view(dt).reshape(self.height, self.width, ch)

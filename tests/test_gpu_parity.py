@@ -292,6 +292,33 @@ def test_error_paths(ctx):
     ctx.upload_scene(wl.buffers)
 
 
+def test_stream_whose_inner_node_ends_the_walk_is_not_packed(ctx):
+    """An empty node whose hit link is -1 (a lone empty root; the reference simply ends the walk there,
+    trace3.cs:226) must not be read as a leaf marker by the packed node form: every pixel misses, after one visit."""
+    wl = workloads.Workload("room", 64, 40)
+    ctx.upload_scene(wl.buffers)
+    root = np.zeros(1, hostlib.NODE_DTYPE)
+    root["min"], root["max"] = [-50, -50, -50], [50, 50, 50]
+    root["hitNext"] = root["missNext"] = -1
+    ctx.upload(3, root)                       # triangles, materials, emitters stay room.obj's
+    ctx.resize(64, 40)
+    for flags in (hiplib.FLAG_AUX, hiplib.FLAG_AUX | hiplib.FLAG_PER_PIXEL_KERNEL):
+        ctx.clear()
+        ctx.trace_samples(wl.rays, wl.eye, spp=2, max_bounces=3, flags=flags, num_emitters=wl.num_emitters)
+        assert (ctx.readback(hiplib.IMAGE_TRIDX) == -1).all() and (ctx.readback(hiplib.IMAGE_VISITS) == 1).all()
+        col = ctx.readback(hiplib.IMAGE_COLOR)
+        assert np.array_equal(col[..., :3], np.broadcast_to(np.float32([0.89, 0.96, 1.0]), col[..., :3].shape))
+    # cyclic links pass the range check but cannot hang the GPU: the walk is capped at the node count
+    loop = np.zeros(2, hostlib.NODE_DTYPE)
+    loop["min"], loop["max"] = [-50, -50, -50], [50, 50, 50]
+    loop["hitNext"], loop["missNext"] = [1, 0], [-1, -1]
+    ctx.upload(3, loop)
+    ctx.trace_samples(wl.rays, wl.eye, spp=1, max_bounces=1, flags=hiplib.FLAG_AUX, num_emitters=wl.num_emitters,
+                      max_follows=1 << 30)
+    assert (ctx.readback(hiplib.IMAGE_TRIDX) == -1).all() and (ctx.readback(hiplib.IMAGE_VISITS) == 3).all()
+    ctx.upload_scene(wl.buffers)
+
+
 @pytest.mark.parametrize("scene,w,h,spp,mb", [("room", 240, 135, 3, 5), ("scene", 400, 225, 4, 5)])
 def test_fast_shadows_flag_gives_the_same_picture(ctx, scene, w, h, spp, mb):
     """RT_FLAG_FAST_SHADOWS (opt-in, not the reference's algorithm): shadow rays that miss their light are not

@@ -1,0 +1,157 @@
+"""The class mirror of raytracer_amd/host/ as a SOURCE-level drop-in: a translation unit
+holding the statements of the reference's main() that touch the hot path (reference src/main.cpp:32-69, 86-90, with
+glm spelt as the reference spells it) must compile and link against raytracer_amd/host/ + librt_host.so unchanged.
+No GPU here: the program is built, and run only far enough to see it fail loudly when the GPU launcher cannot be
+loaded (there is no CPU fallback).  Also: the host's tiling rule equals raytracer_amd/parallel.py's, and the
+input-handler state machine (glfw_setter.hpp) follows reference src/glfw_setter.cpp:77-237."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracer_amd import assets, hostlib, parallel
+from tests.util import ROOT
+
+HOST = os.path.join(ROOT, "raytracer_amd", "host")
+LIBDIR = os.path.join(ROOT, "raytracer_amd", "lib")
+
+# The statements of reference src/main.cpp:32-33,37-40,42-51,54-61,69,86-93 as INTEGRATION.md section A prints them
+# (GLFW / text / quad lines left out; `GlfwSetter::x = &tracer.y` kept: the members must exist and be addressable).
+MAIN_TU = r'''
+#include <iostream>
+#include "BVH.hpp"
+#include "Camera.hpp"
+#include "ComputeShader.hpp"
+#include "Framebuffer.hpp"
+#include "Material.hpp"
+#include "ModelLoader.hpp"
+#include "QTable.hpp"
+#include "Tracer.hpp"
+#include "filter.hpp"
+#include "glfw_setter.hpp"
+namespace glm = rtm;
+#define WIDTH 512
+#define HEIGHT 512
+int main(int argc, char** argv)
+{
+	if(argc < 2)
+	{
+		std::cout << "Usage:\t" << argv[0] << "\tobj_file_path"<< std::endl;
+		return -1;
+	}
+	FrameBuffer framebuffer(WIDTH, HEIGHT);
+	Filter filter(WIDTH, HEIGHT, framebuffer.texture, framebuffer.normalTex, framebuffer.posTex);
+	GlfwSetter::framebuffer = &framebuffer;
+	FrameBuffer framebufferfinal(WIDTH, HEIGHT);
+
+	ModelLoader loader(argv[1]);
+	QTable qt(loader.numObjs);
+	qt.makeVoronoi(loader.triangles_per_obj);
+	BVHContainer bvh(loader.triangles, loader.materialsVector, loader.emitters, qt.normal_per_voronoi, qt.voronoi_centres);
+
+	Camera camera(
+		glm::vec3(0.0, 2.2, 3.5),
+		glm::vec3(0.0, 3.0, 0.0),
+		glm::vec3(0.0, 1.0, 0.0),
+		60.0,
+		WIDTH,
+		HEIGHT,
+		1.0f,
+		2.0f
+	);
+	GlfwSetter::camera = &camera;
+
+	Tracer tracer(&camera, &framebuffer, &bvh, &qt);
+	GlfwSetter::importanceSampled = &tracer.importanceSampled;
+	GlfwSetter::useBlueNoise = &tracer.useBlueNoise;
+	GlfwSetter::maxAccumulateSamples = &tracer.maxAccumulateSamples;
+	GlfwSetter::accumulateSamples = &tracer.accumulateSamples;
+	GlfwSetter::freezeTime = &tracer.freezeTime;
+	GlfwSetter::iterations = &filter.iterations;
+	GlfwSetter::maxBounces = &tracer.maxBounces;
+
+	for(int i = 0; i < 2; i++)
+	{
+		tracer.trace(GlfwSetter::frameNumber);
+		if(GlfwSetter::filter)
+		{
+			filter.filter();
+			filter.setTextureRead();
+		} else
+		{
+			framebuffer.setTextureRead();
+		}
+		framebufferfinal.renderToFramebuffer();
+		framebufferfinal.renderToScreen();
+		GlfwSetter::frameNumber++;
+	}
+	framebuffer.saveToImage("image.png");
+	return 0;
+}
+'''
+
+
+def test_reference_main_statements_compile_against_the_mirror(tmp_path):
+    src = tmp_path / "main_ref.cpp"
+    src.write_text(MAIN_TU)
+    exe = tmp_path / "main_ref"
+    r = subprocess.run(["g++", "-std=c++17", "-Wall", "-I", HOST, str(src), "-o", str(exe), "-L", LIBDIR, "-lrt_host",
+                        f"-Wl,-rpath,{LIBDIR}", "-ldl", "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # no GPU launcher to load: the program must stop with the loud error, not fall back to anything
+    env = dict(os.environ, RT_HIP_LIB=str(tmp_path / "no_such_librt_hip.so"))
+    run = subprocess.run([str(exe), assets.path("room.obj")], capture_output=True, text=True, env=env, timeout=60)
+    assert run.returncode != 0
+    assert "GPU LAUNCHER NOT LOADED" in run.stderr and "no CPU fallback" in run.stderr
+
+
+def test_host_tiling_rule_equals_parallel_py():
+    for w, h, world, halo in [(1920, 1080, 8, 57), (1920, 1080, 4, 57), (1920, 1080, 2, 57), (3840, 2160, 8, 57),
+                              (1920, 1080, 1, 57), (64, 2000, 4, 11), (1920, 1080, 7, 57), (1920, 1080, 8, 0),
+                              (1000, 563, 3, 25), (1000, 563, 6, 1), (48, 40, 2, 11), (5, 3, 8, 0)]:
+        for rank in range(world):
+            rect, grid = hostlib.tile_rect(w, h, world, rank, halo)
+            assert grid == parallel.tile_grid(w, h, world, halo), (w, h, world, halo)
+            assert rect == parallel.tile_rect(w, h, world, rank, halo), (w, h, world, rank)
+
+
+def test_input_state_machine_follows_glfw_setter():
+    cam0 = dict(hostlib.REFERENCE_CAMERA)
+    K = hostlib.KEYS
+    # W: a 0.1 step along the horizontal part of the view direction, lookAt moves with the eye, frameNumber -> 0
+    cam, fn, mb, it, fo, ex = hostlib.input_event(cam0, 17, 5, 2, False, key=K["W"])
+    d = np.array(cam0["look_at"], np.float32) - np.array(cam0["eye"], np.float32)
+    step = (d / np.linalg.norm(d) * np.float32(0.1)).astype(np.float32)
+    step[1] = 0
+    assert fn == 0 and (mb, it, fo) == (5, 2, False)
+    assert np.allclose(np.array(cam["eye"]) - np.array(cam0["eye"]), step, atol=1e-6)
+    assert np.allclose(np.array(cam["look_at"]) - np.array(cam0["look_at"]), step, atol=1e-6)
+    # S undoes W
+    back, fn, *_ = hostlib.input_event(cam, 3, 5, 2, False, key=K["S"])
+    assert fn == 0 and np.allclose(back["eye"], cam0["eye"], atol=1e-6)
+    # the room's walls: no step beyond |x|, |z| = 5
+    edge = dict(cam0, eye=(4.95, 2.2, 0.0), look_at=(6.0, 2.2, 0.0))
+    stuck, fn, *_ = hostlib.input_event(edge, 9, 5, 2, False, key=K["W"])
+    assert stuck["eye"] == pytest.approx(edge["eye"]) and fn == 0
+    # Z / X: up and down, never below y = 0
+    up, fn, *_ = hostlib.input_event(cam0, 4, 5, 2, False, key=K["Z"])
+    assert fn == 0 and up["eye"][1] == pytest.approx(2.3) and up["look_at"][1] == pytest.approx(3.1)
+    low = dict(cam0, eye=(0.0, 0.05, 3.5))
+    down, fn, *_ = hostlib.input_event(low, 4, 5, 2, False, key=K["X"])
+    assert down["eye"][1] == pytest.approx(0.05)
+    # COMMA / PERIOD: maxBounces +1 / -1 (not below 2), accumulation restarts
+    assert hostlib.input_event(cam0, 8, 5, 2, False, key=K["COMMA"])[1:3] == (0, 6)
+    assert hostlib.input_event(cam0, 8, 2, 2, False, key=K["PERIOD"])[1:3] == (0, 2)
+    # SPACE / MINUS / EQUAL / 1 / 2 do NOT restart the accumulation
+    _, fn, mb, it, fo, ex = hostlib.input_event(cam0, 8, 5, 2, False, key=K["SPACE"])
+    assert (fn, fo) == (8, True)
+    assert hostlib.input_event(cam0, 8, 5, 1, True, key=K["MINUS"])[3] == 1
+    assert hostlib.input_event(cam0, 8, 5, 2, True, key=K["EQUAL"])[3] == 3
+    assert hostlib.input_event(cam0, 8, 5, 2, True, key=K["K1"])[5] == pytest.approx(1.1)
+    assert hostlib.input_event(cam0, 8, 5, 2, True, exposure=0.05, key=K["K2"])[5] == 0.0
+    # scroll: fov clamped to [45, 100], restart only when it changed
+    cam, fn, *_ = hostlib.input_event(cam0, 8, 5, 2, False, scroll=5.0)
+    assert cam["fov"] == 55.0 and fn == 0
+    cam, fn, *_ = hostlib.input_event(dict(cam0, fov=45.0), 8, 5, 2, False, scroll=3.0)
+    assert cam["fov"] == 45.0 and fn == 8

@@ -54,11 +54,6 @@ class CheckerBackend:
         a = np.ascontiguousarray(self._img(image)[y0:y1, x0:x1])
         return torch.from_numpy(a.view(np.uint8).reshape(y1 - y0, -1).copy())
 
-    def write_rect(self, image, rect, tensor):
-        x0, y0, x1, y1 = rect
-        img = self._img(image)
-        img[y0:y1, x0:x1] = tensor.numpy().view(img.dtype).reshape(y1 - y0, x1 - x0, 4)
-
 
 def _free_port():
     with socket.socket() as s:
@@ -80,7 +75,7 @@ def _worker(rank, world, port, out_path):
     frame.render(0)
     frame.gather(dist)
     if rank == 0:
-        np.save(out_path, b.filtered.view(np.uint16))
+        np.save(out_path, frame.result().view(np.uint16))
     dist.barrier()
     dist.destroy_process_group()
 
