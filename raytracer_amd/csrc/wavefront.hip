@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     int chunkNext = (int)min(myFirst, (long long)total), chunkEnd = (int)min(myFirst + chunk, (long long)total);
     bool exhausted = total <= 0 || chunkNext >= total;
     WT(const long long wt0 = wall_clock64(); const long long wc0 = clock64();
-       long long wtRefill = 0, wtWalkC = 0, wtSetup = 0, wtRounds = 0, wtFinish = 0, wtTail = 0;
+       long long wtRefill = 0, wtWalkC = 0, wtcSetup = 0, wtRounds = 0, wtFinish = 0, wtTail = 0;
        int wtOuter = 0, wtCoop = 0, wtPairs = 0, wtWalk = 0, wtRetest = 0;)
 
     for (;;) {
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                WT(const long long c3 = clock64(); wtSetup += c3 - c2;)
+                WT(const long long c3 = clock64(); wtcSetup += c3 - c2;)
                 // rounds of 64 pairs; the triangle of the next round is requested before this round's is tested
                 const unsigned long long atOrBelow = (2ull << lane) - 1ull;
                 int rankBase = -1; // rank of the last ray that starts before this round
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         if (lane == 0 && stage < 8) {
             long long *o = rtWaveTrace[stage][min((int)(blockIdx.x * 4 + (threadIdx.x >> 6)), 8191)];
             o[0] = wt0; o[1] = wall_clock64(); o[2] = r; o[3] = wtOuter; o[4] = wtCoop; o[5] = wtPairs; o[6] = wtWalk;
-            o[7] = raysPerWave; o[8] = clock64() - wc0; o[9] = wtRefill; o[10] = wtWalkC; o[11] = wtSetup; o[12] = wtRounds;
+            o[7] = raysPerWave; o[8] = clock64() - wc0; o[9] = wtRefill; o[10] = wtWalkC; o[11] = wtcSetup; o[12] = wtRounds;
             o[13] = wtFinish; o[14] = wtTail; o[15] = wtRetest;
         }
     })

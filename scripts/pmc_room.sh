@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$REPO/gpurun_out/pmc_room_${1:-x}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $REPO/bench.py --scene room --steps 2 --warmup 1 --no-cpu-baseline"
+BENCH="python3 $REPO/bench.py --scene room --steps 2 --warmup 2 --no-cpu-baseline --cases none"
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d "$OUT/sq" -- $BENCH > "$OUT/sq.log" 2>&1 || { echo failed; tail -5 "$OUT/sq.log"; exit 1; }
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM --output-format csv -d "$OUT/sq2" -- $BENCH > "$OUT/sq2.log" 2>&1 || { echo failed2; tail -5 "$OUT/sq2.log"; }
 python3 - "$OUT" <<'PY'
