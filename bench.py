@@ -75,7 +75,7 @@ def cpu_baseline(wl, spp, max_bounces, filter_iters, max_follows=1000, budget_s=
                       f"traced {repeats}x in {t_trace:.2f} s each, {filter_iters} filter passes on the full frame in {t_filter:.2f} s"}
 
 
-def roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key):
+def roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, root_misses=0):
     """Roofline of the kernel that took most device time, per launch, from HIP events recorded on the kernel's own
     stream (rt_profile).  Algorithmic work follows SURVEY.md 8(d): per traversal 25 ops + 48 B per node visit,
     51 ops + 48 B per triangle test; filter 36 B (pass 0) / 28 B per pixel and pass.  Which roof applies is decided
@@ -92,27 +92,25 @@ def roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key):
     avg_ms = tm.ms[didx] / max(launches, 1)
     hot = 32 * wl.info.num_nodes + 48 * wl.info.num_triangles
     resident = hot <= L2_RESIDENT_BYTES
-    primary_rays = float(cnt.paths)
-    sec_visits, sec_tests = cnt.node_visits - cnt.primary_node_visits, cnt.tri_tests - cnt.primary_tri_tests
+    # Traversals run in the extend kernels (stage 0 = the primary rays that enter the scene's bounding box, traced once
+    # per pixel); the classify kernel only does the root-box test: a primary ray that misses that box is one ray of one
+    # node visit, counted there (root_misses per frame).
+    classified = float(root_misses) * steps
+    ext_rays, ext_visits, ext_tests = cnt.rays - classified, cnt.node_visits - classified, float(cnt.tri_tests)
     ops = 0.0
-    if dominant == "wf_extend" and not resident:
-        # beyond the L2s the primary rays that enter the scene box are walked by the extend kernel too (stage 0)
-        alg_bytes = 48.0 * (cnt.node_visits + cnt.tri_tests) + 48.0 * cnt.rays
-        ops = 25.0 * cnt.node_visits + 51.0 * cnt.tri_tests
-        kname = "rt_wf_extend_kernel"
-    elif dominant == "wf_extend":  # every non-primary traversal; reads a 32 B ray, writes a 16 B hit per ray
-        alg_bytes = 48.0 * (sec_visits + sec_tests) + 48.0 * (cnt.rays - primary_rays)
-        ops = 25.0 * sec_visits + 51.0 * sec_tests
-        kname = "rt_wf_extend_kernel"
+    if dominant == "wf_extend":    # reads a 32 B ray, writes a 16 B hit per ray
+        alg_bytes = 48.0 * (ext_visits + ext_tests) + 48.0 * ext_rays
+        ops = 25.0 * ext_visits + 51.0 * ext_tests
+        kname = "rt_wf_extend_rows_kernel" if (resident and wl.info.num_nodes <= 896) else "rt_wf_extend_kernel"
     elif dominant == "per_pixel":
         alg_bytes = (48.0 * (cnt.node_visits + cnt.tri_tests) + 160.0 * cnt.shaded_hits + 28.0 * cnt.paths +
                      16.0 * cnt.paths * (spp - 1) / max(spp, 1))
         ops = 25.0 * cnt.node_visits + 51.0 * cnt.tri_tests
         kname = "rt_trace3_kernel"
-    elif dominant == "wf_primary":  # primary traversals + G-buffer / radiance writes (28 B per pixel-sample)
-        alg_bytes = 48.0 * (cnt.primary_node_visits + cnt.primary_tri_tests) + 28.0 * cnt.paths
-        ops = 25.0 * cnt.primary_node_visits + 51.0 * cnt.primary_tri_tests
-        kname = "rt_wf_primary_kernel"
+    elif dominant == "wf_primary":  # root-box test per pixel + G-buffer / radiance writes for the pixels that miss it
+        alg_bytes = 48.0 * classified + 28.0 * classified + 32.0 * (float(W * H) * steps - classified)
+        ops = 25.0 * float(W * H) * steps
+        kname = "rt_wf_classify_kernel"
     elif dominant == "filter":     # 36 B per pixel in pass 0, 28 B in later passes
         alg_bytes = float(W * H) * (36.0 + 28.0 * (filter_iters - 1)) * steps
         kname = "rt_atrous_kernel"
@@ -203,10 +201,11 @@ def run_case(K, parallel, ctx, device, wl, scene_key, W, H, spp, bounces, filter
            "rays_per_frame": rays_per_frame, "node_visits_per_frame": cnt.node_visits / steps,
            "tri_tests_per_frame": cnt.tri_tests / steps,
            "hit_pixel_fraction": round(hit, 5),
-           "rays_past_root_per_frame": rays_per_frame - float(spp * stop_at_root),
+           "rays_past_root_per_frame": rays_per_frame - float(stop_at_root),
+           "rays_per_frame_if_primary_per_sample": rays_per_frame + float((spp - 1) * W * H),
            "walk_stop": ctx.walk_stop(), "schedule_settle_frames": settle,
            "kernel_ms_per_frame": {K.TIME_NAMES[i]: round(tm.ms[i] / steps, 4) for i in range(8) if tm.launches[i]},
-           "roofline": roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key)}
+           "roofline": roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, stop_at_root)}
     if cpu_budget_s > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(wl, spp, bounces, filter_iters, max_follows, cpu_budget_s)
@@ -432,7 +431,7 @@ def main():
     frame_rays = sums[14]
     ms_per_step = elapsed * 1e3 / a.steps
     mrays = frame_rays * a.steps / elapsed / 1e6
-    rl = roofline(K, tm, cnt, wl, W, H, a.spp, a.filter, a.steps, scene_key)
+    rl = roofline(K, tm, cnt, wl, W, H, a.spp, a.filter, a.steps, scene_key, stop_at_root or 0)
     frame_name = f"{scene_key}{'.obj' if not lattice else ''} {W}x{H} {a.spp}spp"
     headline = (a.scene, W, H, a.spp, a.bounces, a.filter) == ("scene", 1920, 1080, 4, 5, 5)
     out = {
@@ -462,7 +461,8 @@ def main():
     }
     if hit is not None:
         out["hit_pixel_fraction"] = round(hit, 5)
-        out["rays_past_root_per_frame"] = frame_rays - float(a.spp * stop_at_root)
+        out["rays_past_root_per_frame"] = frame_rays - float(stop_at_root)
+        out["rays_per_frame_if_primary_per_sample"] = frame_rays + float((a.spp - 1) * W * H)
     if frame_sha is not None:
         out["frame_sha256"] = frame_sha
     if fast_ms is not None:

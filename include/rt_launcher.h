@@ -195,8 +195,8 @@ int rt_trace_batch(rt_ctx *ctx, const rt_trace_params *params, int n, const rt_r
 /* rt_trace_batch for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  NO counterpart in the reference (its GL driver allocates behind every call).
  * Same kernels, same arguments and same images as rt_trace_batch with RT_KERNEL_TRACE3 (the wavefront pipeline), but
- * the pipeline's scratch memory — path state, ray queue, queue counters, per-sample radiance: 408 B per path slot —
- * is a fixed file-scope device array of the library (27.3 MB, held by every GPU the library runs on until the
+ * the pipeline's scratch memory — path state, ray queue, queue counters, per-sample radiance: 412 B per path slot —
+ * is a fixed file-scope device array of the library (27.5 MB, held by every GPU the library runs on until the
  * process ends) instead of buffers grown with hipMalloc.  The call performs no hipMalloc / hipFree / event creation
  * and does not record profiling spans.
  * Limit: tile pixels x n <= rt_static_max_paths() (65 536 path slots, e.g. a 256 x 256 tile at 1 sample or 128 x 128

@@ -31,6 +31,8 @@ struct rt_ctx {
 
     // scene
     DevBuf boxes, leaves, tris48, tris128, mtls, emitters, raw[11], tables[5];
+    DevBuf spec;          // decision-tree table of the row-mode walk (RtScene::spec); hasSpec says whether it is valid
+    bool hasSpec = false;
     int numNodes = 0, numTris = 0, numMtls = 0, numEmitters = 0;
     int maxTriEnd = 0; // largest firstTri+numTris over the nodes, checked against numTris at launch
 
@@ -40,7 +42,7 @@ struct rt_ctx {
     int filteredIndex = -1; // which of filt[] holds the result of the last rt_filter
 
     // wavefront path tracer state (wavefront.h), grown on demand
-    DevBuf wfState[8], wfRay[6], wfQueue[2], wfCounts, wfRadiance;
+    DevBuf wfState[8], wfRay[6], wfQueue[2], wfCounts, wfRadiance, wfPrimPix;
     size_t wfCapacity = 0, wfRadianceSlots = 0;
     int tuneRefillLanes = 0, tuneExtendBlocks = 4;  // development knobs: RT_WF_REFILL (0: by scene size), RT_WF_BLOCKS
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
@@ -55,11 +57,22 @@ struct rt_ctx {
         int choice = 8;       // walkStop in use once decided
         hipEvent_t ev[2] = {nullptr, nullptr};
     } walkTune;
+    // Queue sizes of the previous frame (read back asynchronously into pinned memory): the host cannot know how many
+    // rays a stage of the frame it is launching will hold, but frames of one scene resemble each other, so the sizes of
+    // the last frame choose each stage's extend kernel (row mode for sparse stages).  Never changes the picture.
+    int *hostCounts = nullptr;          // pinned, 32 ints
+    hipEvent_t countsEvent = nullptr;
+    bool countsPending = false, havePrediction = false;
+    int predictedCounts[32] = {};
+    long long predictionKey = -1;       // tile / batch / bounces the prediction belongs to
     int lastWalkStop = 0;      // what the most recent wavefront launch used ...
     bool lastWalkSettled = false; // ... and whether that was a settled choice (rt_walk_stop)
     int tuneMinRays = 4;                             // RT_WF_MIN_RAYS: floor of the rays-per-wave rule
     int tuneCoopA = 8, tuneCoopB = 12;               // RT_WF_COOP_A / _B: the per-round rule of WfParams::coopA
-    int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 2, tuneChunk = 64, tunePrimaryBlocks = 32, tunePrimaryVia = -1;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
+    int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 2, tuneChunk = 64;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
+    int tuneLongWalk = 0;                            // RT_WF_LONG_WALK (WfParams::longWalk)
+    int tuneRowStaticK = 8, tuneRowChunkDiv = 2;     // RT_WF_ROW_STATIC, RT_WF_ROW_CHUNK_DIV (WfParams::rowStaticK / rowChunkDiv)
+    int tuneRowMode = -1, tuneRowMaxRays = -1;       // RT_WF_ROWS (0 never, 1 always, 2 per stage by ray count), RT_WF_ROW_MAX_RAYS
     int tuneCacheNodes = 896;                        // RT_WF_CACHE_NODES: 28 KB + 12 KB of wave scratch per block, 4 blocks per CU
 
     // multi-GPU gather over RCCL (rt_comm.hip)

@@ -11,6 +11,7 @@
 //   tris48  float4[3*T]   triangle j → {v0,0}, {v1-v0,0}, {v2-v0,0}                      48 B, 16-B aligned
 //   tris128 the reference's 128-B triangle records, untouched (normals, mtlIndex, ...)   shading only
 //   mtls    the reference's 32-B material records; emitters: 128-B records
+//   spec    uint16[32*N] decision-tree table of the row-mode walk (small packed trees only, see RtScene::spec)
 // A 32-B box record never straddles a 64-B/128-B line (the reference's 48-B records do); the
 // intersection loops read 48 B per triangle instead of the first 48 B of a 128-B stride.
 //
@@ -61,7 +62,16 @@ struct RtScene {
     // (reference BVH.cpp:223-241), so a prefix of the node array is exactly the top levels every ray walks.
     int cacheNodes;
     int packedLeaves; // boxes are in the packed form (see the layout above)
+    // Decision-tree table of the row-mode walk (wavefront.hip), only for packed trees small enough to live in LDS
+    // (numNodes <= RT_SPEC_MAX_NODES), else null: 32 uint16 per node n.  Heap position p stands for the node reached
+    // from n by the decisions p spells (0 = n itself; 2p+1 = after "enter" at p, 2p+2 = after "skip" at p; a leaf's two
+    // successors are the same node).  Entries 1..14: the node at position p (with n itself the 15 nodes a round tests
+    // at once), 15..30: the nodes the walk can stand on after four decisions; 0xFFFF = the walk has ended there.
+    // Entry 0: bit p set = position p (0..14) has a node; entry 31: bit p set = that node is a leaf.
+    const uint16_t *spec;
 };
+#define RT_SPEC_MAX_NODES 896
+#define RT_SPEC_STRIDE 32
 
 struct RtImages {
     float4 *color;   // RGBA32F

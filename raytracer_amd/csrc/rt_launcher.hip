@@ -52,8 +52,8 @@ constexpr size_t kStaticRay8 = alignUp((size_t)3 * RT_STATIC_MAX_PATHS * 8);    
 constexpr size_t kStaticQueue = alignUp((size_t)RT_STATIC_MAX_PATHS * 4);         // queue[2]
 constexpr size_t kStaticCounts = alignUp(64 * sizeof(int));
 constexpr size_t kStaticRadiance = alignUp((size_t)RT_STATIC_MAX_PATHS * 16);
-constexpr size_t kStaticBytes = 7 * kStaticState16 + kStaticState8 + 5 * kStaticRay16 + kStaticRay8 + 2 * kStaticQueue +
-                                kStaticCounts + kStaticRadiance;
+constexpr size_t kStaticBytes = 7 * kStaticState16 + kStaticState8 + 5 * kStaticRay16 + kStaticRay8 + 3 * kStaticQueue +
+                                kStaticCounts + kStaticRadiance; // (3 queues: two path queues + the stage-0 pixel queue)
 } // namespace
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 #define RT_MAX_DEVICES 64
@@ -191,12 +191,21 @@ int rt_create(int device_id, rt_ctx **out) {
         }
         rtStaticScratchPtr[device_id] = ptr;
     }
+    if (hipHostMalloc((void **)&c->hostCounts, 32 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&c->countsEvent, hipEventDisableTiming) != hipSuccess) {
+        (void)hipStreamDestroy(c->ownStream);
+        delete c;
+        return RT_ENOMEM;
+    }
     if (const char *e = std::getenv("RT_WF_REFILL")) c->tuneRefillLanes = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_CACHE_NODES")) c->tuneCacheNodes = std::max(0, std::min(3800, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_RAYS_PER_WAVE")) c->tuneRaysPerWave = std::max(0, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_FILL")) c->tuneFill = std::max(1, std::min(64, std::atoi(e)));
-    if (const char *e = std::getenv("RT_WF_PRIMARY_BLOCKS")) c->tunePrimaryBlocks = std::max(1, std::min(1 << 20, std::atoi(e)));
-    if (const char *e = std::getenv("RT_WF_PRIMARY_VIA_EXTEND")) c->tunePrimaryVia = std::atoi(e);
+    if (const char *e = std::getenv("RT_WF_ROWS")) c->tuneRowMode = std::max(0, std::min(2, std::atoi(e)));
+    if (const char *e = std::getenv("RT_WF_ROW_MAX_RAYS")) c->tuneRowMaxRays = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("RT_WF_LONG_WALK")) c->tuneLongWalk = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("RT_WF_ROW_STATIC")) c->tuneRowStaticK = std::max(0, std::min(64, std::atoi(e)));
+    if (const char *e = std::getenv("RT_WF_ROW_CHUNK_DIV")) c->tuneRowChunkDiv = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_CHUNK")) c->tuneChunk = std::max(8, std::min(65536, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_COOP")) c->tuneCoop = std::atoi(e);
     if (const char *e = std::getenv("RT_WF_WALK_STOP")) c->tuneWalkStop = std::max(0, std::min(8, std::atoi(e)));
@@ -220,6 +229,8 @@ void rt_destroy(rt_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     rtCommRelease(c);
+    if (c->countsEvent) (void)hipEventDestroy(c->countsEvent);
+    if (c->hostCounts) (void)hipHostFree(c->hostCounts);
     for (TimedSpan &s : c->spans) {
         (void)hipEventDestroy(s.start);
         (void)hipEventDestroy(s.stop);
@@ -229,7 +240,7 @@ void rt_destroy(rt_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     DevBuf *all[] = {&c->boxes, &c->leaves, &c->tris48, &c->tris128, &c->mtls, &c->emitters, &c->color, &c->normal,
                      &c->pos, &c->filt[0], &c->filt[1], &c->tridx, &c->visits, &c->stats, &c->ldr, &c->counters,
-                     &c->wfQueue[0], &c->wfQueue[1], &c->wfCounts, &c->wfRadiance};
+                     &c->wfQueue[0], &c->wfQueue[1], &c->wfCounts, &c->wfRadiance, &c->wfPrimPix, &c->spec};
     for (DevBuf &b : c->wfState) releaseBuf(b);
     for (DevBuf &b : c->wfRay) releaseBuf(b);
     for (DevBuf *b : all) releaseBuf(*b);
@@ -260,6 +271,7 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
         c->walkTune.state = 0;
         c->walkTune.pending = false;
         c->lastWalkSettled = false;
+        c->havePrediction = false;
         if (nbytes % sizeof(RtNode48)) return fail(c, RT_EINVAL, "rt_upload: node stream is not a multiple of 48 bytes");
         const size_t n = nbytes / sizeof(RtNode48);
         if (n == 0 || n > 0x7FFFFFFFu / 2) return fail(c, RT_EINVAL, "rt_upload: node count out of range");
@@ -303,6 +315,36 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
             leaves[i] = make_int2(s.firstTri, s.numTris);
         }
         if (maxEnd > 0x7FFFFFFF) return fail(c, RT_ECORRUPT, "rt_upload: triangle range overflow");
+        // decision-tree table of the row-mode walk (RtScene::spec): trees that fit LDS whole, packed form only
+        c->hasSpec = false;
+        if (packed && n <= RT_SPEC_MAX_NODES) {
+            std::vector<uint16_t> spec(n * RT_SPEC_STRIDE, 0xFFFF);
+            for (size_t i = 0; i < n; ++i) {
+                int t[31];
+                t[0] = (int)i;
+                for (int q = 0; q < 15; ++q) {
+                    const int at = t[q];
+                    if (at < 0) {
+                        t[2 * q + 1] = t[2 * q + 2] = -1;
+                    } else {
+                        const RtNode48 &s = src[at];
+                        t[2 * q + 1] = s.numTris > 0 ? s.missNext : s.hitNext; // after "enter" (a leaf's links are equal)
+                        t[2 * q + 2] = s.missNext;                             // after "skip"
+                    }
+                }
+                unsigned validMask = 0, leafMask = 0; // over the 15 positions a round tests
+                for (int q = 0; q < 15; ++q) {
+                    if (t[q] < 0) continue;
+                    validMask |= 1u << q;
+                    if (src[t[q]].numTris > 0) leafMask |= 1u << q;
+                }
+                for (int q = 1; q < 31; ++q) spec[i * RT_SPEC_STRIDE + q] = t[q] < 0 ? (uint16_t)0xFFFF : (uint16_t)t[q];
+                spec[i * RT_SPEC_STRIDE] = (uint16_t)validMask;        // (position 0 is node i itself)
+                spec[i * RT_SPEC_STRIDE + 31] = (uint16_t)leafMask;
+            }
+            if ((r = uploadTo(c, c->spec, spec.data(), spec.size() * sizeof(uint16_t)))) return r;
+            c->hasSpec = true;
+        }
         if ((r = uploadTo(c, c->boxes, boxes.data(), boxes.size() * sizeof(float4)))) return r;
         if ((r = uploadTo(c, c->leaves, leaves.data(), leaves.size() * sizeof(int2)))) return r;
         c->numNodes = (int)n;
@@ -405,6 +447,7 @@ int rt_resize(rt_ctx *c, int width, int height) {
     c->walkTune.state = 0;
     c->walkTune.pending = false;
     c->lastWalkSettled = false;
+    c->havePrediction = false;
     c->width = width;
     c->height = height;
     return rt_clear(c);
@@ -425,6 +468,7 @@ void fillScene(const rt_ctx *c, RtScene &sc, RtImages &img) {
     sc.numEmitters = c->emitters.p ? c->numEmitters : 0;
     sc.cacheNodes = 0;
     sc.packedLeaves = c->packedLeaves ? 1 : 0;
+    sc.spec = c->hasSpec ? (const uint16_t *)c->spec.p : nullptr;
     img.color = (float4 *)c->color.p;
     img.normal = (uint32_t *)c->normal.p;
     img.pos = (uint2 *)c->pos.p;
@@ -449,6 +493,7 @@ int ensureWavefront(rt_ctx *c, size_t capacity, size_t radianceSlots, WfBuffers 
             if ((r = ensure(c, c->wfRay[k], 3 * cap * 16))) return r;
         if ((r = ensure(c, c->wfRay[5], 3 * cap * 8))) return r;
         if ((r = ensure(c, c->wfQueue[0], cap * 4)) || (r = ensure(c, c->wfQueue[1], cap * 4))) return r;
+        if ((r = ensure(c, c->wfPrimPix, cap * 4))) return r;
         c->wfCapacity = cap;
     }
     if ((r = ensure(c, c->wfCounts, 64 * sizeof(int)))) return r;
@@ -474,6 +519,7 @@ int ensureWavefront(rt_ctx *c, size_t capacity, size_t radianceSlots, WfBuffers 
     wf.queue[1] = (int *)c->wfQueue[1].p;
     wf.counts = (int *)c->wfCounts.p;
     wf.radiance = (float4 *)c->wfRadiance.p;
+    wf.primPix = (unsigned *)c->wfPrimPix.p;
     wf.capacity = (int)c->wfCapacity;
     return RT_OK;
 }
@@ -520,8 +566,11 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     // or, when the scene is beyond the L2s and there is no locality to keep, as soon as half of them are
     wp.refillLanes = c->tuneRefillLanes > 0 ? c->tuneRefillLanes : (hot > (size_t)3 * 1024 * 1024 ? 32 : 64);
     wp.extendBlocksPerCU = c->tuneExtendBlocks;
-    wp.primaryBlocksPerCU = c->tunePrimaryBlocks;
-    wp.primaryViaExtend = c->tunePrimaryVia >= 0 ? c->tunePrimaryVia : (hot > (size_t)3 * 1024 * 1024 ? 1 : 0);
+    wp.rowMode = c->tuneRowMode >= 0 ? c->tuneRowMode : 2;
+    wp.rowMaxRays = c->tuneRowMaxRays >= 0 ? c->tuneRowMaxRays : 65536;
+    wp.longWalk = c->tuneLongWalk;
+    wp.rowStaticK = c->tuneRowStaticK;
+    wp.rowChunkDiv = c->tuneRowChunkDiv;
     wp.extendCacheNodes = c->tuneCacheNodes;
     wp.extendRaysPerWave = c->tuneRaysPerWave;
     wp.extendFill = c->tuneFill;
@@ -573,12 +622,29 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         if (!wt.ev[1]) wt.ev[1] = takeEvent(c);
         HIP_TRY(c, hipEventRecord(wt.ev[0], c->stream));
     }
+    // the previous frame's queue sizes, if they have arrived and belong to the same kind of frame
+    const long long key = ((long long)(r.x1 - r.x0) << 40) ^ ((long long)(r.y1 - r.y0) << 20) ^ ((long long)r.x0 << 10) ^
+                          (long long)r.y0 ^ ((long long)n << 56) ^ ((long long)p->maxBounces << 60) ^ ((long long)p->flags << 32);
+    if (c->countsPending && hipEventQuery(c->countsEvent) == hipSuccess) {
+        std::memcpy(c->predictedCounts, c->hostCounts, sizeof c->predictedCounts);
+        c->countsPending = false;
+        c->havePrediction = true;
+    }
+    const int *predicted = (c->havePrediction && c->predictionKey == key) ? c->predictedCounts : nullptr;
     const bool profiled = c->profile && !noAlloc;
     rt_ctx *spanCtx = c;
     SpanGuard span(spanCtx, TK_TRACE, profiled);
     hipError_t e = rtLaunchWavefront(sc, img, wp, wf, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream,
-                                     profiled ? c : nullptr);
+                                     profiled ? c : nullptr, predicted);
     span.end();
+    if (e == hipSuccess && !c->countsPending) { // (one read-back in flight at a time: hostCounts is a single buffer)
+        if (hipMemcpyAsync(c->hostCounts, wf.counts, 32 * sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+            hipEventRecord(c->countsEvent, c->stream) == hipSuccess) {
+            c->countsPending = true;
+            c->predictionKey = key;
+            c->havePrediction = false; // until this read-back has arrived
+        }
+    }
     if (timeIt) {
         HIP_TRY(c, hipEventRecord(wt.ev[1], c->stream));
         wt.pending = true;
@@ -785,6 +851,7 @@ int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const
     wf.rayWork = (int2 *)take(kStaticRay8);
     wf.queue[0] = (int *)take(kStaticQueue);
     wf.queue[1] = (int *)take(kStaticQueue);
+    wf.primPix = (unsigned *)take(kStaticQueue);
     wf.counts = (int *)take(kStaticCounts);
     wf.radiance = (float4 *)take(kStaticRadiance);
     if (off != kStaticBytes) return fail(c, RT_ESTATE, "rt_trace_batch_static: scratch carve-up mismatch");

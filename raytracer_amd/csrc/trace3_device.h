@@ -198,6 +198,26 @@ __device__ __forceinline__ void testTriangle(const float4 a0, const float4 a1, c
     }
 }
 
+// The same test as a pure function of one triangle: is it an acceptable hit nearer than `nearest`, and its t, u, v
+// (the operations and values of testTriangle<false>; the division is done for every lane).  For kernels that test
+// the triangles of a leaf in different lanes and then reduce (wavefront.hip, row mode).
+__device__ __forceinline__ bool triangleCandidate(const float4 a0, const float4 a1, const float4 a2, f3 origin, f3 dir,
+                                                  float nearest, float &t, float &u, float &v) {
+    const f3 v0 = xyz(a0), e1 = xyz(a1), e2 = xyz(a2);
+    const f3 pvec = cross(dir, e2);
+    const float det = dot(e1, pvec);
+    const f3 tvec = origin - v0;
+    const float uu = dot(tvec, pvec);
+    const f3 qvec = cross(tvec, e1);
+    const float vv = dot(dir, qvec);
+    const bool inside = !(det < 0.0f) & !(uu < 0.0f || uu > det) & !(vv < 0.0f || (uu + vv) > det);
+    const float invDet = 1.0f / det;
+    t = dot(e2, qvec) * invDet;
+    u = uu * invDet;
+    v = vv * invDet;
+    return inside && t >= 0.0f && t < nearest;
+}
+
 // intersectTriangles (trace3.cs:172-186) over [first, end): triangles are tested strictly in index
 // order, four records (12 aligned 16-byte loads) are requested before the first of them is tested so
 // that the load latency of a leaf is paid once per four triangles instead of once per triangle.

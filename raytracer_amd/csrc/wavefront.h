@@ -14,8 +14,12 @@ struct WfParams {
     float eye[3], ray00[3], ray01[3], ray10[3], ray11[3];
     int maxBounces, numEmitters, maxFollows, flags, batch;
     int refillLanes;       // a wave takes new rays when refillLanes/64 of its ray lanes are free (64 = all)
-    int primaryViaExtend;   // primary rays that enter the scene box are walked by the extend kernel (stage 0)
-    int primaryBlocksPerCU; // the primary kernel's blocks walk over the 16x16 tiles; this many blocks per CU
+    int longWalk;           // extend: a wave holding a ray with more node visits than this runs at raised priority (0: off)
+    int rowMode;            // extend: 1 = the row-mode kernel (needs RtScene::spec), 0 = the lane-per-ray kernel,
+                            // 2 = per stage: row mode for stages predicted to hold at most rowMaxRays rays
+    int rowMaxRays;
+    int rowStaticK;         // row mode: queue entries per wave handed out by position before the shared cursor is used
+    int rowChunkDiv;        // row mode: cursor chunk = remaining rays / (resident waves * rowChunkDiv), clamped to 4..64
     int extendBlocksPerCU; // persistent 256-thread blocks per CU of the extend kernel
     int extendCacheNodes;  // nodes the extend kernel keeps in LDS (32 bytes each, per block)
     int extendRaysPerWave; // 0 = chosen per launch from the queue size; 1..64 forces it (development knob)
@@ -48,14 +52,17 @@ struct WfBuffers {
     int2 *rayWork;      // visits, tests of that traversal
     int *queue[2];      // path ids, ping-pong
     int *counts;        // [0..31] queue sizes per stage, [32..63] work cursors per stage
+    unsigned *primPix;  // stage-0 queue: pixel index of entry j (one entry per PIXEL: the primary ray is the same for
+                        // every sample of a batch, trace3.cs:805-806, so it is traced once and logic(0) fans out)
     float4 *radiance;   // [sample][pixel in tile] finished L
     int capacity;
     int tilePixels;
 };
 
+// predictedCounts: queue sizes per stage of a similar earlier frame (32 ints), or null when there is none
 hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfParams &p, const WfBuffers &wf,
                              const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream,
-                             void *profileCtx);
+                             void *profileCtx, const int *predictedCounts);
 void rtMarkKernel(void *ctxOpaque, int kind, bool begin);
 // bytes of device memory per unit of capacity (one path slot) and per (sample, tile pixel)
 size_t rtWavefrontBytesPerPath();

@@ -7,10 +7,14 @@
 // lanes whose paths have ended idle inside their wave.  Here a frame (a batch of 1..16 samples) is a
 // short sequence of launches over compacted queues:
 //
-//   primary   one lane per (pixel, sample), 8x8 pixel tiles per wave: ray generation + closest hit;
-//             misses finish immediately (sky), hits are appended to the path queue
+//   classify  one lane per PIXEL, 8x8 pixel tiles per wave: ray generation + the root-box test.  The primary ray does
+//             not depend on the sample (un-jittered, trace3.cs:805-806), so it is generated once per pixel: rays that
+//             miss the scene's bounding box finish here for every sample of the batch (sky), the others are
+//             appended to the stage-0 ray queue, one entry per pixel
+//   extend 0  closest hit of the queued primary rays (one traversal per pixel)
 //   for bounce b = 0 .. maxBounces:
-//     logic   one lane per queued path: resolve the two shadow rays of bounce b-1 (MIS direct light),
+//     logic   one lane per queued path (b = 0: one lane per (queued pixel, sample): the fan-out of the shared primary
+//             hit into the batch's path slots): resolve the two shadow rays of bounce b-1 (MIS direct light),
 //             shade the hit of bounce b (emission, G-buffer at b = 0), stop or emit THREE rays —
 //             light-sample shadow ray, BRDF-sample shadow ray, continuation ray — and re-queue
 //     extend  persistent waves pull rays from the ray queue and walk the BVH; the three rays of a path are traced
@@ -93,132 +97,82 @@ __device__ __forceinline__ void flushCounters(const WfParams &p, RtCountersDev *
 
 } // namespace
 
-// ------------------------------------------------------------------------------------------ primary
-template <int NODES, bool WATERTIGHT>
-__global__ __launch_bounds__(256) void rt_wf_primary_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
-                                                            rt_rect tile, int tilesX, int tilesY, int xcdRemap,
-                                                            int logicalBlocks, RtCountersDev *counters) {
-    const int tilesPerSample = tilesX * tilesY;
+// ------------------------------------------------------------------------------------------ classify
+__global__ __launch_bounds__(256) void rt_wf_classify_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
+                                                             rt_rect tile, int tilesX, int tilesY, int xcdRemap,
+                                                             int logicalBlocks, RtCountersDev *counters) {
+    const int ntiles = tilesX * tilesY;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = (lane & 7) + 8 * (wave & 1), ly = (lane >> 3) + 8 * (wave >> 1);
     const int W = img.width, H = img.height;
     const int perXcd = logicalBlocks / 8;
-    const int cacheWanted = sc.cacheNodes;
-    bool cacheFilled = false;
-    sc.cacheNodes = 0;
-    unsigned nPaths = 0, nRays = 0, nVisits = 0, nTests = 0;
-    // A block walks over several 16x16 tiles: most tiles of the named scenes only see the sky and take a few
-    // hundred cycles, less than it costs to start a block for each.
+    unsigned nPixels = 0, nMissed = 0;
+    const float4 b0 = sc.boxes[0], b1 = sc.boxes[1];
+    const f3 eye = ld3(p.eye);
+    // A block walks over several 16x16 tiles: a tile costs a few hundred cycles, less than starting a block for it.
     for (int b = blockIdx.x; b < logicalBlocks; b += gridDim.x) {
-    const int t = xcdRemap ? (b % 8) * perXcd + b / 8 : b;
-    const bool live = t < tilesPerSample * p.batch;
-    const int sample = live ? t / tilesPerSample : 0;
-    const int ts = t - sample * tilesPerSample;
-    const int x = tile.x0 + (ts % tilesX) * 16 + lx, y = tile.y0 + (ts / tilesX) * 16 + ly;
-    const bool active = live && x < tile.x1 && y < tile.y1;
-
-    PathCtx c = makeCtx(p, x, y, sample, 0);
-    bool queued = false;
-    Hit h;
-    h.tridx = -1;
-    h.t = h.u = h.v = 0.0f;
-    f3 dir = F3(0, 0, 0);
-    f3 invdir = F3(0, 0, 0);
-    bool entersScene = false;
-    if (active) {
-        // trace3.cs:805-807
-        const float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
-        dir = normalize(mix(mix(ld3(p.ray00), ld3(p.ray01), pyf), mix(ld3(p.ray10), ld3(p.ray11), pyf), pxf));
-        invdir = rcp3(dir);
-        // does this ray get past the root?  (the same box test the walk starts with)
-        const float4 b0 = sc.boxes[0], b1 = sc.boxes[1];
-        const f3 eye = ld3(p.eye);
-        const float m1x = (b0.x - eye.x) * invdir.x, m1y = (b0.y - eye.y) * invdir.y, m1z = (b0.z - eye.z) * invdir.z;
-        const float m2x = (b1.x - eye.x) * invdir.x, m2y = (b1.y - eye.y) * invdir.y, m2z = (b1.z - eye.z) * invdir.z;
-        const bool ltx = invdir.x < 0.0f, lty = invdir.y < 0.0f, ltz = invdir.z < 0.0f;
-        const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
-        const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
-        entersScene = maxt >= 0.0f && mint <= maxt * 1.00000024f;
-    }
-    // Only blocks that see the scene's bounding box copy the top of the tree into LDS (a few per cent of the
-    // tiles for the named scenes under the survey's camera); the other tiles finish after their one root test.
-    if (cacheWanted > 0 && !cacheFilled) {
-        if (__syncthreads_or(entersScene)) {
-            sc.cacheNodes = cacheWanted;
-            fillNodeCache(sc);
-            cacheFilled = true;
+        const int t = xcdRemap ? (b % 8) * perXcd + b / 8 : b;
+        const bool live = t < ntiles;
+        const int x = tile.x0 + (t % tilesX) * 16 + lx, y = tile.y0 + (t / tilesX) * 16 + ly;
+        const bool active = live && x < tile.x1 && y < tile.y1;
+        f3 dir = F3(0, 0, 0);
+        bool entersScene = false;
+        if (active) {
+            // trace3.cs:805-807
+            const float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
+            dir = normalize(mix(mix(ld3(p.ray00), ld3(p.ray01), pyf), mix(ld3(p.ray10), ld3(p.ray11), pyf), pxf));
+            const f3 invdir = rcp3(dir);
+            // does this ray get past the root?  (the box test the walk starts with, geometry.glsl:66-76)
+            const float m1x = (b0.x - eye.x) * invdir.x, m1y = (b0.y - eye.y) * invdir.y, m1z = (b0.z - eye.z) * invdir.z;
+            const float m2x = (b1.x - eye.x) * invdir.x, m2y = (b1.y - eye.y) * invdir.y, m2z = (b1.z - eye.z) * invdir.z;
+            const bool ltx = invdir.x < 0.0f, lty = invdir.y < 0.0f, ltz = invdir.z < 0.0f;
+            const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
+            const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
+            entersScene = maxt >= 0.0f && mint <= maxt * 1.00000024f;
         }
-    }
-    // p.primaryViaExtend: rays that get past the root are not walked here but queued for the extend kernel
-    // (stage 0), which has the cooperative leaf tests and coalesced triangle reads that pay off for scenes beyond
-    // the caches; rays that miss the root box finish here as before (one node visit).
-    const bool defer = p.primaryViaExtend && entersScene;
-    if (active) {
-        if (!entersScene) { // the walk would stop at the root, which was tested above: one ray, one node visit
-            c.lastIterations = 1;
-            c.rays = 1;
-            c.visits = 1;
-        } else if (!defer) { // (the LDS copy of the nodes exists: a lane of this block enters the scene)
-            traverse<NODES, WATERTIGHT>(sc, c, ld3(p.eye), dir, invdir, h);
-        }
-        const size_t pix = (size_t)y * W + x;
-        if ((p.flags & RT_FLAG_AUX) && !defer) {
-            img.tridx[pix] = h.tridx;
-            img.visits[pix] = c.lastIterations;
-        }
-        if (defer) {
-            queued = true;
-        } else if (h.tridx == -1) {
-            // trace(): L += beta * SKY_COLOR; write(vec3(0), vec3(0)); break   (trace3.cs:639-647)
+        if (active && !entersScene) {
+            // the walk stops at the root: one ray, one node visit, a miss.
+            // trace(): L += beta * SKY_COLOR; write(vec3(0), vec3(0)); break   (trace3.cs:639-647), for every sample
+            const size_t pix = (size_t)y * W + x;
             const f3 L = F3(0, 0, 0) + F3(1, 1, 1) * F3(0.89f, 0.96f, 1.00f);
-            // every sample of the batch would store the same G-buffer texel (the primary ray does not depend on
-            // the sample); the last one does it, as successive dispatches would leave it
-            if (sample == p.batch - 1) {
-                img.normal[pix] = 0u;
-                img.pos[pix] = make_uint2(pack_half2_rtz(0.0f, 0.0f), pack_half2_rtz(0.0f, 1.0f));
-            }
+            img.normal[pix] = 0u;
+            img.pos[pix] = make_uint2(pack_half2_rtz(0.0f, 0.0f), pack_half2_rtz(0.0f, 1.0f));
             const int tp = (y - tile.y0) * (tile.x1 - tile.x0) + (x - tile.x0);
-            wf.radiance[(size_t)sample * wf.tilePixels + tp] = make_float4(L.x, L.y, L.z, 1.0f);
-            // the statistics image shows the last sample of the batch, as successive dispatches would leave it
-            if ((p.flags & RT_FLAG_PIXEL_STATS) && sample == p.batch - 1)
-                img.stats[pix] = make_int4((int)c.rays, (int)c.visits, (int)c.tests, 0);
-        } else {
-            queued = true;
+            // w = -1 marks "every sample of the batch has this radiance": only sample 0 is stored (rt_wf_blend_kernel)
+            wf.radiance[tp] = make_float4(L.x, L.y, L.z, -1.0f);
+            if (p.flags & RT_FLAG_AUX) {
+                img.tridx[pix] = -1;
+                img.visits[pix] = 1;
+            }
+            if (p.flags & RT_FLAG_PIXEL_STATS) img.stats[pix] = make_int4(1, 1, 0, 0);
         }
+        const bool queued = active && entersScene;
+        const int slot = waveAppend(&wf.counts[0], queued);
+        if (queued) {
+            // stage-0 ray queue: one entry per pixel, in the continuation-ray segment
+            wf.primPix[slot] = (unsigned)(y * W + x);
+            const size_t r = (size_t)2 * wf.capacity + slot;
+            wf.rayO[0][r] = make_float4(p.eye[0], p.eye[1], p.eye[2], 1.0f);
+            wf.rayD[0][r] = make_float4(dir.x, dir.y, dir.z, 0.0f);
+        }
+        nPixels += active ? 1u : 0u;
+        nMissed += (active && !entersScene) ? 1u : 0u;
     }
-    const int slot = waveAppend(&wf.counts[0], queued);
-    if (queued) {
-        // path id = queue position at stage 0; the primary ray sits in the continuation-ray segment
-        wf.queue[0][slot] = slot;
-        wf.pixSample[slot] = make_uint2((unsigned)(y * W + x), (unsigned)sample);
-        wf.L_seed[slot] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(0));
-        wf.beta[slot] = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(0));
-        const size_t r = (size_t)2 * wf.capacity + slot;
-        wf.rayO[0][r] = make_float4(p.eye[0], p.eye[1], p.eye[2], 1.0f);
-        wf.rayD[0][r] = make_float4(dir.x, dir.y, dir.z, 0.0f);
-        wf.rayHit[r] = make_int4(h.tridx, __float_as_int(h.t), __float_as_int(h.u), __float_as_int(h.v));
-        if (p.flags & RT_FLAG_PIXEL_STATS) wf.pathStats[slot] = make_int4((int)c.rays, (int)c.visits, (int)c.tests, 0);
-    }
-    nPaths += active ? 1u : 0u;
-    nRays += (active && !defer) ? 1u : 0u;
-    nVisits += c.visits;
-    nTests += c.tests;
-    }
-    if (!(p.flags & RT_FLAG_NO_COUNTERS)) { // one primary ray per path: three sums feed six counters
+    if (!(p.flags & RT_FLAG_NO_COUNTERS)) {
         RtCountersDev *cs = counterShard(counters);
-        unsigned n = nPaths, r = nRays, v = nVisits, t = nTests;
+        unsigned n = nPixels, m = nMissed;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             n += __shfl_down(n, off, 64);
-            r += __shfl_down(r, off, 64);
-            v += __shfl_down(v, off, 64);
-            t += __shfl_down(t, off, 64);
+            m += __shfl_down(m, off, 64);
         }
         if (lane == 0 && n) {
-            if (r) atomicAdd(&cs->rays, (unsigned long long)r);
-            atomicAdd(&cs->paths, (unsigned long long)n);
-            if (v) { atomicAdd(&cs->node_visits, (unsigned long long)v); atomicAdd(&cs->primary_visits, (unsigned long long)v); }
-            if (t) { atomicAdd(&cs->tri_tests, (unsigned long long)t); atomicAdd(&cs->primary_tests, (unsigned long long)t); }
+            atomicAdd(&cs->paths, (unsigned long long)n * (unsigned)p.batch); // pixel-samples
+            if (m) { // traversals executed here: one ray of one node visit per pixel that misses the root box
+                atomicAdd(&cs->rays, (unsigned long long)m);
+                atomicAdd(&cs->node_visits, (unsigned long long)m);
+                atomicAdd(&cs->primary_visits, (unsigned long long)m);
+            }
         }
     }
 }
@@ -241,7 +195,9 @@ __device__ __forceinline__ float lightDistance(const LightTri &t, f3 origin, f3 
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void rt_wf_logic_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
                                                           rt_rect tile, int bounce, RtCountersDev *counters) {
-    const int n = min(wf.counts[bounce], wf.capacity);
+    // bounce 0: the stage-0 queue holds one entry per pixel (the shared primary hit); every sample of the batch becomes
+    // a path of its own here: lane i = (entry i / batch, sample i % batch), path id = i
+    const int n = bounce == 0 ? min(wf.counts[0] * p.batch, wf.capacity) : min(wf.counts[bounce], wf.capacity);
     const int *qin = wf.queue[bounce & 1];
     int *qout = wf.queue[(bounce + 1) & 1];
     const size_t cap = (size_t)wf.capacity;
@@ -262,17 +218,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         SI.tridx = -1; SI.matidx = 0; SI.normal = SI.point = F3(0, 0, 0);
         int4 stats = make_int4(0, 0, 0, 0);
         if (have) {
-            pid = qin[i];
-            const uint2 ps = wf.pixSample[pid];
-            pix = (int)ps.x;
-            sample = (int)ps.y;
-            const float4 Ls = wf.L_seed[pid];
-            const float4 bt = wf.beta[pid];
-            L = F3(Ls.x, Ls.y, Ls.z);
-            beta = F3(bt.x, bt.y, bt.z);
-            seed = __float_as_int(Ls.w);
-            const int flags = __float_as_int(bt.w);
-            if (wantStats) stats = wf.pathStats[pid];
+            int flags = 0;
+            size_t hitRay = 2 * cap + i; // where this path's continuation (or primary) ray and its hit are
+            if (bounce == 0) {
+                const int entry = i / p.batch;
+                sample = i - entry * p.batch;
+                pid = i;
+                pix = (int)wf.primPix[entry];
+                beta = F3(1.0f, 1.0f, 1.0f);
+                hitRay = 2 * cap + entry;
+            } else {
+                pid = qin[i];
+                const uint2 ps = wf.pixSample[pid];
+                pix = (int)ps.x;
+                sample = (int)ps.y;
+                const float4 Ls = wf.L_seed[pid];
+                const float4 bt = wf.beta[pid];
+                L = F3(Ls.x, Ls.y, Ls.z);
+                beta = F3(bt.x, bt.y, bt.z);
+                seed = __float_as_int(Ls.w);
+                flags = __float_as_int(bt.w);
+                if (wantStats) stats = wf.pathStats[pid];
+            }
 
             if (flags & WF_FLAG_PENDING) {
                 // finish EstimateDirect of the previous bounce (trace3.cs:533-571) and L += beta * Ld (:652)
@@ -299,18 +266,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 
             if (!(flags & WF_FLAG_ENDED)) {
                 // the hit of this bounce: result of the continuation (or primary) ray
-                const size_t r = 2 * cap + i;
+                const size_t r = hitRay;
                 const int4 hr = wf.rayHit[r];
                 const float4 ro = wf.rayO[bounce & 1][r], rd = wf.rayD[bounce & 1][r];
                 const f3 origin = F3(ro.x, ro.y, ro.z);
                 dir = F3(rd.x, rd.y, rd.z);
-                if (wantStats && (bounce > 0 || p.primaryViaExtend)) {
+                if (wantStats) { // (at bounce 0 every sample's statistics include the shared primary traversal)
                     const int2 w2 = wf.rayWork[r];
                     stats.x += 1;
                     stats.y += w2.x;
                     stats.z += w2.y;
                 }
-                if (bounce == 0 && p.primaryViaExtend && (p.flags & RT_FLAG_AUX)) { // the primary walk ran in the extend kernel
+                if (bounce == 0 && (p.flags & RT_FLAG_AUX) && sample == p.batch - 1) {
                     img.tridx[pix] = hr.x;
                     img.visits[pix] = wf.rayWork[r].x;
                 }
@@ -381,6 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const bool alive = continuePath(c, bounce, SI.normal, m, dir, beta, wi);
             outO[2 * cap + slot] = make_float4(o2.x, o2.y, o2.z, alive ? 1.0f : 0.0f);
             outD[2 * cap + slot] = make_float4(wi.x, wi.y, wi.z, 0.0f);
+            if (bounce == 0) wf.pixSample[pid] = make_uint2((unsigned)pix, (unsigned)sample);
             wf.L_seed[pid] = make_float4(L.x, L.y, L.z, __int_as_float(c.seed));
             wf.beta[pid] = make_float4(beta.x, beta.y, beta.z, __int_as_float(WF_FLAG_PENDING | (alive ? 0 : WF_FLAG_ENDED)));
             if (wantStats) wf.pathStats[pid] = stats;
@@ -426,7 +394,8 @@ template <int NODES, bool WATERTIGHT>
 __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams p, WfBuffers wf, int stage,
                                                            int refillLanes, RtCountersDev *counters) {
     const int n = min(wf.counts[stage], wf.capacity);
-    // stage 0 (deferred primary rays) holds one ray per path, in the continuation segment; later stages three
+    // stage 0 (the primary rays that enter the scene box) holds one ray per pixel, in the continuation segment; later
+    // stages three per path
     const int kinds = stage == 0 ? 1 : 3, kindBase = stage == 0 ? 2 : 0;
     const int total = kinds * n;
     const size_t cap = (size_t)wf.capacity;
@@ -534,6 +503,12 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         if (!__any(active)) {
             if (exhausted) break;
             continue;
+        }
+        // A launch lasts as long as its longest ray, and a wave that shares its SIMD with three others advances at a
+        // fraction of the speed it has alone: waves that hold a long walk go first.
+        if (p.longWalk > 0) {
+            if (__any(active && iterations > p.longWalk)) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
         }
         WT(wtOuter++; const int wtIt0 = iterations; const long long c1 = clock64(); wtRefill += c1 - c0;)
 
@@ -730,6 +705,295 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     }
 }
 
+// ------------------------------------------------------------------------------------------ extend, row mode
+// The walk of intersectGeometry is one chain of dependent steps per ray, and the frames of the named scenes are bound by
+// the longest chains, not by throughput (a ray that runs inside the object enters ~45 leaves and visits ~300 nodes;
+// measured: ~590 cycles per node step and ~3 400 cycles per leaf in the lane-per-ray kernel above, whose lanes mostly
+// wait).  Row mode spends the idle lanes on the chain itself: a wave holds FOUR rays, one per row of 16 lanes.
+//   * Walk: the 15 nodes that the next four decisions can reach from the current node (a decision tree: "enter" ->
+//     hitNext, "skip" -> missNext) are listed per node in a table built at upload (RtScene::spec, in LDS next to the
+//     node records), together with two static masks: which of the 15 exist, which are leaves.  Lane j of the row
+//     tests the box of candidate j; ONE ballot gives the 15 outcomes to every lane, a dozen bit operations follow the
+//     path the reference's loop takes through them, and a find-first-set stops it at the first leaf it enters or at
+//     the end of the walk.  Up to four node visits per round for the latency of one; visits are counted as the
+//     decisions actually taken, so `iterations` (and the MAX_FOLLOWS abort) are the reference's.
+//   * Leaf: lane j tests triangles first + j and first + 16 + j (triangleCandidate: the operations of
+//     geometry.glsl:31-51), the row's closest accepted hit is found with DPP row rotations — smallest t, then smallest
+//     index among equal t: what the reference's strict `<` scan keeps (trace3.cs:177) — no LDS, no atomics, no re-test.
+// Needs the whole tree and its table in LDS (packed records, numNodes <= RT_SPEC_MAX_NODES: the named scenes).
+#define ROW_DPP_ROR(n) (0x120 + (n))
+__device__ __forceinline__ unsigned rowMinU32(unsigned v) { // min over the 16 lanes of a row, in every lane of it
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ROW_DPP_ROR(8), 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ROW_DPP_ROR(4), 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ROW_DPP_ROR(2), 0xF, 0xF, false));
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, ROW_DPP_ROR(1), 0xF, 0xF, false));
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfParams p, WfBuffers wf, int stage,
+                                                                 RtCountersDev *counters) {
+    const int n = stage == 0 ? min(wf.counts[0], wf.capacity) : min(wf.counts[stage], wf.capacity);
+    const int kinds = stage == 0 ? 1 : 3, kindBase = stage == 0 ? 2 : 0;
+    const int total = kinds * n;
+    const size_t cap = (size_t)wf.capacity;
+    const int lane = threadIdx.x & 63, rowLane = lane & 15, rowShift = lane & 48;
+    const float4 *rayO = wf.rayO[stage & 1], *rayD = wf.rayD[stage & 1];
+    const bool wantWork = (p.flags & RT_FLAG_PIXEL_STATS) != 0 || (stage == 0 && (p.flags & RT_FLAG_AUX) != 0);
+    int *cursor = &wf.counts[32 + stage];
+    // LDS: node records, then the decision-tree table
+    const int N = sc.numNodes;
+    for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) rtLdsNodes[i] = sc.boxes[i];
+    uint4 *specLds4 = reinterpret_cast<uint4 *>(rtLdsNodes + 2 * N);
+    const uint4 *spec4 = reinterpret_cast<const uint4 *>(sc.spec);
+    for (int i = threadIdx.x; i < 4 * N; i += blockDim.x) specLds4[i] = spec4[i];
+    const unsigned short *specLds = reinterpret_cast<const unsigned short *>(specLds4);
+    __syncthreads();
+
+    // per-row ray state, held by all 16 lanes of the row
+    bool active = false, bounded = false;
+    size_t slot = 0;
+    f3 origin = F3(0, 0, 0), dir = F3(0, 0, 0), invdir = F3(0, 0, 0);
+    bool ltx = false, lty = false, ltz = false;
+    int next = -1, iterations = 0, hitTri = -1;
+    unsigned tests = 0;
+    float nearest = 0.0f, hitT = 0.0f, hitU = 0.0f, hitV = 0.0f;
+    unsigned cRays = 0, cVisits = 0, cTests = 0; // totals, kept by the first lane of each row
+
+    // Queue.  Every wave first takes entries by position, strided over the waves (wave w: w, w + W, w + 2W, ...: a
+    // sparse stage is spread over all resident waves without one atomic, and an atomic on one address retires at only
+    // ~90 per microsecond); what lies beyond staticK entries per wave is handed out in chunks by the shared cursor.
+    const int residentWaves = (int)gridDim.x * (int)(blockDim.x >> 6);
+    const int myWave = blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+    const int staticK = (int)min((long long)p.rowStaticK, ((long long)total + residentWaves - 1) / residentWaves);
+    const long long staticEnd = min((long long)total, (long long)staticK * residentWaves);
+    // small chunks keep the tail of the launch balanced (a chunk is worked off four rays at a time)
+    const int chunk = (int)min(64ll, max(4ll, ((long long)total - staticEnd) / ((long long)residentWaves * p.rowChunkDiv)));
+    int kNext = 0;                 // next static entry of this wave
+    int chunkNext = 0, chunkEnd = 0; // this wave's current piece of the dynamic part
+    bool exhausted = total <= 0;
+    WT(const long long wt0 = wall_clock64(); const long long wc0 = clock64();
+       long long wtRefill = 0, wtWalkC = 0, wtLeaf = 0, wtTail = 0, wtLoad = 0, wtTest = 0; int wtOuter = 0, wtRounds = 0, wtLeaves = 0;)
+
+    for (;;) {
+        WT(const long long c0 = clock64();)
+        // ---- rows without a ray take the next queue entries
+        const unsigned long long idleRows = __ballot(!active && rowLane == 0);
+        if (!exhausted && idleRows) {
+            const int rank = __popcll(idleRows & ((1ull << rowShift) - 1ull)); // of this row among the idle rows
+            int w = -1;
+            if (kNext < staticK) {
+                const long long at = (long long)myWave + (long long)(kNext + rank) * residentWaves;
+                if (kNext + rank < staticK && at < staticEnd) w = (int)at;
+                kNext += __popcll(idleRows);
+                if (kNext >= staticK && staticEnd >= (long long)total) exhausted = true;
+            } else {
+                if (chunkNext >= chunkEnd) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(cursor, chunk);
+                    const long long at = staticEnd + (long long)__shfl(base, 0, 64);
+                    chunkNext = (int)min(at, (long long)total);
+                    chunkEnd = (int)min(at + chunk, (long long)total);
+                }
+                if (chunkNext + rank < chunkEnd) w = chunkNext + rank;
+                chunkNext += __popcll(idleRows);
+                if (chunkNext >= chunkEnd && chunkEnd >= total) exhausted = true;
+            }
+            if (!active && w >= 0) {
+                const int kind = w / n, j = w - kind * n;
+                slot = (size_t)(kind + kindBase) * cap + j;
+                const float4 ro = rayO[slot];
+                if (ro.w != 0.0f) {
+                    const float4 rd = rayD[slot];
+                    origin = F3(ro.x, ro.y, ro.z);
+                    dir = F3(rd.x, rd.y, rd.z);
+                    invdir = rcp3(dir);
+                    ltx = invdir.x < 0.0f;
+                    lty = invdir.y < 0.0f;
+                    ltz = invdir.z < 0.0f;
+                    next = 0;
+                    bounded = rd.w > 0.0f; // RT_FLAG_FAST_SHADOWS: look no further than the light
+                    nearest = bounded ? rd.w : __builtin_inff();
+                    iterations = 0;
+                    tests = 0;
+                    hitTri = -1;
+                    hitT = hitU = hitV = 0.0f;
+                    active = true;
+                } else if (wantWork && rowLane == 0) {
+                    wf.rayWork[slot] = make_int2(0, 0); // never cast (path ended by the roulette)
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- walk: rounds of up to four decisions until the row enters a leaf or its walk ends
+        WT(wtOuter++; const long long c1 = clock64(); wtRefill += c1 - c0;)
+        int leafFirst = 0, leafCount = 0;
+        while (active && next != -1 && leafCount == 0) {
+            WT(wtRounds++;)
+            const int tableAt = next * RT_SPEC_STRIDE;
+            // the round's 15 candidate nodes (position 0 is the current node) and the two static masks of this table row
+            const int entry = specLds[tableAt + rowLane];
+            const unsigned vd = specLds[tableAt];                       // positions whose node exists
+            const unsigned leafMask = specLds[tableAt + RT_SPEC_STRIDE - 1]; // positions whose node is a leaf
+            const int cand = rowLane == 0 ? next : min(entry, N - 1);   // (a missing node: any record, masked by vd)
+            const float4 b0 = rtLdsNodes[2 * cand], b1 = rtLdsNodes[2 * cand + 1];
+            const int w1 = __float_as_int(b1.w);
+            const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
+                        m1z = (b0.z - origin.z) * invdir.z;
+            const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
+                        m2z = (b1.z - origin.z) * invdir.z;
+            const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
+            const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
+            // geometry.glsl:66-76 and the pruning test of trace3.cs:238-246
+            const bool enter = maxt >= 0.0f && mint <= maxt * 1.00000024f && !(mint > nearest);
+            const unsigned go = (unsigned)(__ballot(enter) >> rowShift) & vd;
+            if (iterations + 4 <= p.maxFollows) {
+                // the path of the reference's loop through the outcomes: from position q, "enter" leads to 2q+1, else 2q+2
+                const unsigned p1 = 2u - (go & 1u);
+                const unsigned p2 = 2u * p1 + 2u - ((go >> p1) & 1u);
+                const unsigned p3 = 2u * p2 + 2u - ((go >> p2) & 1u);
+                const unsigned p4 = 2u * p3 + 2u - ((go >> p3) & 1u);
+                const unsigned pathMask = 1u | (1u << p1) | (1u << p2) | (1u << p3);
+                // it stops at the first position (positions grow along the path) that has no node or is an entered leaf
+                const unsigned stops = pathMask & (~vd | (go & leafMask));
+                const int q = __ffs((int)stops) - 1; // -1: four decisions taken, none of them a stop
+                const unsigned upTo = q < 0 ? 0xFFFFFFFFu : ((2u << q) - 1u);
+                iterations += __popc(pathMask & vd & upTo);
+                const bool ended = q >= 0 && !((vd >> q) & 1u);
+                const int to = specLds[tableAt + (q < 0 ? (int)p4 : 2 * q + 1)]; // a leaf's successor, or four decisions on
+                next = (ended || to == 0xFFFF) ? -1 : to;
+                if (q >= 0 && !ended) {
+                    const int lw = __shfl(w1, rowShift + q, 64);
+                    leafFirst = lw & 0x03FFFFFF;
+                    leafCount = ((lw >> 26) & 31) + 1;
+                }
+            } else {
+                // within four visits of MAX_FOLLOWS (trace3.cs:227-234): decision by decision, with the abort
+                int pos = 0, state = 0, leafPos = 0; // state: 0 walking, 1 entered a leaf, 2 walk ended, 3 aborted
+#pragma unroll
+                for (int level = 0; level < 4; ++level) {
+                    const bool walking = state == 0;
+                    const bool v = (vd >> pos) & 1u, g = (go >> pos) & 1u, f = g && ((leafMask >> pos) & 1u);
+                    const bool over = iterations + 1 > p.maxFollows;
+                    const bool visit = walking && v;
+                    iterations += visit ? 1 : 0;
+                    if (walking) state = !v ? 2 : over ? 3 : f ? 1 : 0;
+                    if (visit && !over && f) leafPos = pos;
+                    if (visit && !over) pos = 2 * pos + (g ? 1 : 2);
+                }
+                if (state == 3) {
+                    hitTri = -1;
+                    next = -1;
+                    bounded = false; // an aborted walk proves nothing: reported as a miss
+                } else if (state == 2) {
+                    next = -1;
+                } else {
+                    const int to = specLds[tableAt + pos];
+                    next = to == 0xFFFF ? -1 : to;
+                    if (state == 1) {
+                        const int lw = __shfl(w1, rowShift + leafPos, 64);
+                        leafFirst = lw & 0x03FFFFFF;
+                        leafCount = ((lw >> 26) & 31) + 1;
+                    }
+                }
+            }
+        }
+
+        // ---- leaf: 16 triangles per step across the row, closest accepted hit by row reduction
+        WT(const long long c2 = clock64(); wtWalkC += c2 - c1; wtLeaves += __any(active && leafCount > 0) ? 1 : 0;)
+        if (active && leafCount > 0) {
+            const int i0 = leafFirst + rowLane, i1 = i0 + 16;
+            const bool has0 = rowLane < leafCount, has1 = rowLane + 16 < leafCount;
+            float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, d0 = a0, d1 = a0, d2 = a0;
+            if (has0) {
+                a0 = sc.tris48[3 * i0];
+                a1 = sc.tris48[3 * i0 + 1];
+                a2 = sc.tris48[3 * i0 + 2];
+            }
+            if (has1) {
+                d0 = sc.tris48[3 * i1];
+                d1 = sc.tris48[3 * i1 + 1];
+                d2 = sc.tris48[3 * i1 + 2];
+            }
+            WT(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long cl = clock64(); wtLoad += cl - c2;)
+            unsigned bestKey = 0xFFFFFFFFu;
+            float bestT = 0.0f, bestU = 0.0f, bestV = 0.0f;
+            int bestI = 0x7FFFFFFF;
+            float t, u, v;
+            if (has0 && triangleCandidate(a0, a1, a2, origin, dir, nearest, t, u, v)) {
+                bestKey = __float_as_uint(t + 0.0f); // -0.0 is keyed as +0.0
+                bestT = t;
+                bestU = u;
+                bestV = v;
+                bestI = i0;
+            }
+            if (__any(has1)) { // (leaves of more than 16 triangles)
+                if (has1 && triangleCandidate(d0, d1, d2, origin, dir, nearest, t, u, v)) {
+                    const unsigned key = __float_as_uint(t + 0.0f);
+                    if (key < bestKey) { // strict: on equal t the lower index (i0) stays
+                        bestKey = key;
+                        bestT = t;
+                        bestU = u;
+                        bestV = v;
+                        bestI = i1;
+                    }
+                }
+            }
+            WT(const long long ct = clock64(); wtTest += ct - cl;)
+            // smallest t of the row; among equal t the smallest index (trace3.cs:177 keeps the first)
+            const unsigned minKey = rowMinU32(bestKey);
+            if (minKey != 0xFFFFFFFFu) {
+                const int minI = (int)rowMinU32(bestKey == minKey ? (unsigned)bestI : 0x7FFFFFFFu);
+                const unsigned rowBits = (unsigned)(__ballot(bestKey == minKey && bestI == minI) >> rowShift) & 0xFFFFu;
+                const int winner = rowShift + __ffs((int)rowBits) - 1; // the one lane that holds that triangle
+                hitT = __shfl(bestT, winner, 64);
+                hitU = __shfl(bestU, winner, 64);
+                hitV = __shfl(bestV, winner, 64);
+                hitTri = minI;
+                nearest = hitT;
+            }
+            tests += (unsigned)leafCount;
+            if (bounded && hitTri >= 0) next = -1; // any hit nearer than the light settles a shadow ray
+        }
+        // ---- the walk is over: publish the closest hit and free the row
+        WT(const long long c3 = clock64(); wtLeaf += c3 - c2;)
+        if (active && next == -1) {
+            if (rowLane == 0) {
+                const int tri = (bounded && hitTri < 0) ? WF_HIT_UNBLOCKED : hitTri;
+                wf.rayHit[slot] = make_int4(tri, __float_as_int(hitT), __float_as_int(hitU), __float_as_int(hitV));
+                if (wantWork) wf.rayWork[slot] = make_int2(iterations, (int)tests);
+                cRays++;
+                cVisits += (unsigned)iterations;
+                cTests += tests;
+            }
+            active = false;
+        }
+        WT(wtTail += clock64() - c3;)
+    }
+    WT({
+        int r = (int)cRays;
+        for (int o = 32; o; o >>= 1) r += __shfl_xor(r, o, 64);
+        if (lane == 0 && stage < 8) {
+            long long *o = rtWaveTrace[stage][min((int)(blockIdx.x * 16 + (threadIdx.x >> 6)), 8191)];
+            o[0] = wt0; o[1] = wall_clock64(); o[2] = r; o[3] = wtOuter; o[4] = wtLeaves; o[5] = 0; o[6] = wtRounds;
+            o[7] = 4; o[8] = clock64() - wc0; o[9] = wtRefill; o[10] = wtWalkC; o[11] = wtLoad; o[12] = wtLeaf;
+            o[13] = wtTest; o[14] = wtTail; o[15] = 0;
+        }
+    })
+    PathCtx c = makeCtx(p, 0, 0, 0, 0);
+    c.rays = cRays;
+    c.visits = cVisits;
+    c.tests = cTests;
+    flushCounters(p, counters, c, 0u);
+    if (stage == 0 && !(p.flags & RT_FLAG_NO_COUNTERS)) {
+        waveAdd(&counterShard(counters)->primary_visits, cVisits);
+        waveAdd(&counterShard(counters)->primary_tests, cTests);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ blend
 // main()'s accumulation (trace3.cs:808-817), once per sample of the batch, in sample order.
 __global__ __launch_bounds__(256) void rt_wf_blend_kernel(RtImages img, WfParams p, WfBuffers wf, rt_rect tile) {
@@ -740,8 +1004,10 @@ __global__ __launch_bounds__(256) void rt_wf_blend_kernel(RtImages img, WfParams
         const size_t pix = (size_t)y * img.width + x;
         float4 cur = make_float4(0, 0, 0, 0);
         bool loaded = false;
+        const float4 L0 = wf.radiance[tp];
+        const bool allSame = L0.w < 0.0f; // a pixel whose primary ray missed the scene box: one value for the batch
         for (int k = 0; k < p.batch; ++k) {
-            const float4 Lk = wf.radiance[(size_t)k * n + tp];
+            const float4 Lk = (allSame || k == 0) ? L0 : wf.radiance[(size_t)k * n + tp];
             f3 old = F3(0, 0, 0);
             if (p.s[k].blendFactor > 0.0f) {
                 if (!loaded && k == 0) cur = img.color[pix];
@@ -760,31 +1026,25 @@ size_t rtWavefrontBytesPerPath() { return 6 * 16 + 8 + 16 + 3 * (4 * 16 + 16 + 8
 
 hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfParams &p, const WfBuffers &wf,
                              const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream,
-                             void *prof) {
+                             void *prof, const int *predictedCounts) {
     const int tw = tile.x1 - tile.x0, th = tile.y1 - tile.y0;
     if (tw <= 0 || th <= 0 || p.batch <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(wf.counts, 0, 64 * sizeof(int), stream);
     if (e != hipSuccess) return e;
     const int tilesX = (tw + 15) / 16, tilesY = (th + 15) / 16;
-    const int ntiles = tilesX * tilesY * p.batch;
+    const int ntiles = tilesX * tilesY;
     const int nblocks = ((ntiles + 7) / 8) * 8;
-    if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, true);
-    RtScene scPlain = sc, scExtend = sc, scPrimary = sc;
+    RtScene scPlain = sc, scExtend = sc;
     scPlain.cacheNodes = 0;
-    scPrimary.cacheNodes = (sc.packedLeaves && !p.primaryViaExtend) ? std::max(0, std::min(sc.numNodes, std::min(p.extendCacheNodes, 1024))) : 0;
     scExtend.cacheNodes = sc.packedLeaves ? std::max(0, std::min(sc.numNodes, p.extendCacheNodes)) : 0;
     const size_t extendLds = (size_t)scExtend.cacheNodes * 32 + 4 * sizeof(WaveShare);
-    const int primaryBlocks = std::min(nblocks, 256 * p.primaryBlocksPerCU);
     const bool wt = (p.flags & RT_FLAG_WATERTIGHT) != 0; // opt-in variant of the triangle test (trace3_device.h)
-    const int primaryNodes = !sc.packedLeaves ? NODES_ANY
-                             : (scPrimary.cacheNodes >= sc.numNodes && sc.numNodes > 0) ? NODES_PACKED_LDS : NODES_PACKED;
-    auto primaryKernel = primaryNodes == NODES_ANY ? (wt ? rt_wf_primary_kernel<NODES_ANY, true> : rt_wf_primary_kernel<NODES_ANY, false>)
-                         : primaryNodes == NODES_PACKED_LDS
-                             ? (wt ? rt_wf_primary_kernel<NODES_PACKED_LDS, true> : rt_wf_primary_kernel<NODES_PACKED_LDS, false>)
-                             : (wt ? rt_wf_primary_kernel<NODES_PACKED, true> : rt_wf_primary_kernel<NODES_PACKED, false>);
-    hipLaunchKernelGGL(primaryKernel, dim3(primaryBlocks), dim3(256), (size_t)scPrimary.cacheNodes * 32, stream,
-                       scPrimary, img, p, wf, tile, tilesX, tilesY, xcdRemap, nblocks, counters);
+
+    if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, true);
+    hipLaunchKernelGGL(rt_wf_classify_kernel, dim3(std::min(nblocks, 256 * 8)), dim3(256), 0, stream, scPlain, img, p, wf,
+                       tile, tilesX, tilesY, xcdRemap, nblocks, counters);
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, false);
+
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
     const int logicBlocks = 256 * 4, extendBlocks = 256 * p.extendBlocksPerCU;
     // the walk's node fetch is chosen here, once per launch (trace3_device.h: loadNodeT)
@@ -793,22 +1053,33 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
                         : extendNodes == NODES_PACKED_LDS
                             ? (wt ? rt_wf_extend_kernel<NODES_PACKED_LDS, true> : rt_wf_extend_kernel<NODES_PACKED_LDS, false>)
                             : (wt ? rt_wf_extend_kernel<NODES_PACKED, true> : rt_wf_extend_kernel<NODES_PACKED, false>);
-    if (p.primaryViaExtend) {
+    // Row mode (one ray per 16-lane row, speculative walk) needs the tree and its decision table in LDS.
+    const bool rowsPossible = sc.spec && sc.packedLeaves && sc.numNodes <= RT_SPEC_MAX_NODES && !wt;
+    const int rowMode = rowsPossible ? p.rowMode : 0;
+    const size_t rowLds = (size_t)sc.numNodes * (32 + 2 * RT_SPEC_STRIDE);
+    const int rowBlocks = 256; // one 16-wave block per CU (80 VGPRs: a second one would not be resident)
+    auto extend = [&](int stage) {
         if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, true);
-        hipLaunchKernelGGL(extendKernel, dim3(extendBlocks), dim3(256), extendLds, stream, scExtend, p, wf, 0,
-                           p.refillLanes, counters);
+        // rowMode 2: a stage that held few rays in the previous frame is bound by its longest walks, not by throughput
+        bool rows = rowMode == 1;
+        if (rowMode == 2 && predictedCounts) {
+            const long long rays = (long long)predictedCounts[stage] * (stage == 0 ? 1 : 3);
+            rows = rays > 0 && rays <= p.rowMaxRays;
+        }
+        if (rows)
+            hipLaunchKernelGGL(rt_wf_extend_rows_kernel, dim3(rowBlocks), dim3(1024), rowLds, stream, sc, p, wf, stage,
+                               counters);
+        else
+            hipLaunchKernelGGL(extendKernel, dim3(extendBlocks), dim3(256), extendLds, stream, scExtend, p, wf, stage,
+                               p.refillLanes, counters);
         if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, false);
-    }
+    };
+    extend(0);
     for (int b = 0; b <= p.maxBounces; ++b) {
         if (prof) rtMarkKernel(prof, RT_TIME_WF_LOGIC, true);
         hipLaunchKernelGGL(rt_wf_logic_kernel, dim3(logicBlocks), dim3(256), 0, stream, scPlain, img, p, wf, tile, b, counters);
         if (prof) rtMarkKernel(prof, RT_TIME_WF_LOGIC, false);
-        if (b < p.maxBounces) {
-            if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, true);
-            hipLaunchKernelGGL(extendKernel, dim3(extendBlocks), dim3(256), extendLds, stream, scExtend, p, wf, b + 1,
-                               p.refillLanes, counters);
-            if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, false);
-        }
+        if (b < p.maxBounces) extend(b + 1);
     }
     int blendBlocks = (tw * th + 255) / 256;
     if (blendBlocks > 4096) blendBlocks = 4096;

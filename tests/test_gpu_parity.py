@@ -105,11 +105,19 @@ def test_schedules_are_bit_identical(ctx, scene, w, h, spp, mb):
     for kw in (dict(), dict(batch=1), dict(batch=1, flags=hiplib.FLAG_AUX | hiplib.FLAG_PIXEL_STATS | hiplib.FLAG_PER_PIXEL_KERNEL)):
         got = render(ctx, wl, spp, mb, **kw)
         c = ctx.counters()
-        results.append((got, (c.rays, c.node_visits, c.tri_tests, c.shaded_hits, c.paths)))
-    for got, cnt in results[1:]:
-        assert cnt == results[0][1]
+        results.append((got, (c.rays, c.node_visits, c.tri_tests, c.shaded_hits, c.paths),
+                        (c.primary_node_visits, c.primary_tri_tests)))
+    for got, cnt, _ in results[1:]:
         for k in got:
             assert np.array_equal(got[k].view(np.uint8), results[0][0][k].view(np.uint8)), k
+    # counters count the traversals EXECUTED: one dispatch per sample traces the (un-jittered, trace3.cs:805-806)
+    # primary ray of a pixel once per sample, a batch of concurrent samples traces it once per pixel
+    assert results[1][1] == results[2][1]
+    batched, single = results[0][1], results[1][1]
+    assert batched[3:] == single[3:]                                  # shaded hits, paths (pixel-samples)
+    assert single[0] - batched[0] == (spp - 1) * w * h                # rays
+    primary = [int(v) for v in results[0][2]]                         # primary visits / tests of the batched run
+    assert single[1] - batched[1] == (spp - 1) * primary[0] and single[2] - batched[2] == (spp - 1) * primary[1]
 
 
 def test_batch_argument_checks(ctx):
@@ -333,7 +341,7 @@ def test_fast_shadows_flag_gives_the_same_picture(ctx, scene, w, h, spp, mb):
     same = (fast["color"].view(np.uint32) == ref["color"].view(np.uint32)).all(-1).mean()
     assert same > 0.999, same
     assert_radiance_close(ref["color"], fast["color"], f"fast shadows {scene}")
-    assert (c1.rays - c1.paths) < 0.8 * (c0.rays - c0.paths) and c1.node_visits < c0.node_visits  # secondary rays
+    assert (c1.rays - w * h) < 0.8 * (c0.rays - w * h) and c1.node_visits < c0.node_visits  # secondary rays
 
 
 class _CustomWorkload:
