@@ -2,19 +2,22 @@
 //
 // One launch = one pass of reference src/shaders/atrous.fs::main (:19-53) as driven by
 // Filter::filter (reference src/filter.cpp:68-104); rt_launcher.hip runs the pass loop.
-// The dilated 3x3 stencil (taps at ±stepwidth) is LDS-tiled: a 256-thread block produces a
-// 64x4 pixel tile and first stages the 3 x 4 source rows it touches (rows y-s, y, y+s for each of
-// its 4 rows, 64 + 2s columns each) with coalesced row loads; colour is widened to fp32 once
-// while staging, so the 9 taps read LDS only.  Taps outside the image read zero and still take
-// part in the weights, exactly like texelFetch on the reference's oracle platform.
-// Arithmetic is fp32 in the shader's operation order; the result is stored as RGBA16F by
-// truncation (what the oracle's render-target store was measured to do).
+// The dilated 3x3 stencil (taps at +-stepwidth) is LDS-tiled.  The kernel is bound by VALU issue (88 % VALU busy at
+// 1 100 instructions per pixel in the first version), so the design goal is instructions per pixel:
+//   * a 256-thread block produces a TX x TY tile and stages the source rows its taps touch ONCE, already unpacked
+//     to fp32 (snorm8 normals, fp16 positions, fp16 colour of the later passes): a staged texel is unpacked once
+//     instead of once per tap that reads it (nine times);
+//   * the tile shape follows the step width so that few texels are staged per output pixel: 16 x 16 at step 1
+//     (18 x 18 staged: 1.27 per pixel), 32 x 8 at step 3, 256 x 1 beyond (three rows of 256 + 2 step texels);
+//   * a texel whose colour holds a NaN (the shader skips such taps) is marked once while staging;
+//   * the per-pass quotients are multiplications by reciprocals with one fused correction, the three weights of a tap
+//     one exponential (see below).
+// Taps outside the image read zero and still take part in the weights, exactly like texelFetch on the reference's
+// oracle platform.  Arithmetic is fp32 in the shader's operation order; the result is stored as RGBA16F by truncation
+// (what the oracle's render-target store was measured to do).
 #include "rt_device.h"
 
-#define FT_X 64
-#define FT_Y 4
 #define FT_MAXSTEP 63
-#define FT_MAXCOLS (FT_X + 2 * FT_MAXSTEP)
 
 namespace {
 
@@ -46,50 +49,76 @@ __device__ __forceinline__ float divUniform(float x, float d, float rd) {
 } // namespace
 
 // colorF32 != nullptr: pass 0 (reads the RGBA32F accumulation image); else reads colorF16.
+// BANDS: the tile is lower than the step, so the three tap rows of a pixel row lie in three separate bands of TY
+// rows (staged rows: 3 TY); otherwise one contiguous band of TY + 2 step rows.
+template <int TX, int TY, bool BANDS>
 __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict__ colorF32,
                                                         const uint2 *__restrict__ colorF16,
                                                         const uint32_t *__restrict__ normal,
                                                         const uint2 *__restrict__ pos, uint2 *__restrict__ out, int W,
                                                         int H, rt_rect rect, int tilesX, float c_phi, float n_phi,
                                                         float p_phi, int step) {
+    static_assert(TX * TY == 256, "one pixel per thread");
     extern __shared__ __align__(16) unsigned char lds[];
-    const int cols = FT_X + 2 * step;
-    float4 *sCol = reinterpret_cast<float4 *>(lds);                       // [12][cols]
-    uint2 *sPos = reinterpret_cast<uint2 *>(sCol + 12 * cols);            // [12][cols]
-    uint32_t *sNrm = reinterpret_cast<uint32_t *>(sPos + 12 * cols);      // [12][cols]
+    const int cols = TX + 2 * step;
+    const int rows = BANDS ? 3 * TY : TY + 2 * step;
+    float4 *sCol = reinterpret_cast<float4 *>(lds);  // [rows][cols] colour; x = NaN marks "skip this tap"
+    float4 *sNrm = sCol + rows * cols;                // normal xyz as fp32 (w of the stored normals is always 0)
+    float4 *sPos = sNrm + rows * cols;                // position xyzw as fp32
 
     const int tileId = blockIdx.x;
-    const int x0 = rect.x0 + (tileId % tilesX) * FT_X, y0 = rect.y0 + (tileId / tilesX) * FT_Y;
+    const int x0 = rect.x0 + (tileId % tilesX) * TX, y0 = rect.y0 + (tileId / tilesX) * TY;
 
-    // stage: LDS row (o+1)*4 + r holds image row y0 + r + o*step, columns x0 - step ... x0 + 63 + step
-    for (int e = threadIdx.x; e < 12 * cols; e += 256) {
+    // Staging in two sweeps: first every global load of this thread's texels is issued (one trip to memory for all of
+    // them: large steps leave room for few blocks per CU, so the latency is not hidden by other blocks), then they
+    // are unpacked and written to LDS.
+    constexpr int kMaxTexels = BANDS ? (3 * TY * (TX + 2 * FT_MAXSTEP) + 255) / 256 : ((TY + 8) * (TX + 8) + 255) / 256;
+    float4 cv[kMaxTexels];
+    uint2 cvh[kMaxTexels], pvh[kMaxTexels];
+    uint32_t nvr[kMaxTexels];
+    bool inside[kMaxTexels];
+#pragma unroll
+    for (int k = 0; k < kMaxTexels; ++k) {
+        const int e = threadIdx.x + 256 * k;
         const int row = e / cols, c = e - row * cols;
-        const int o = row / 4 - 1, r = row & 3;
-        const int sy = y0 + r + o * step, sx = x0 - step + c;
-        float4 cv = make_float4(0, 0, 0, 0);
-        uint2 pv = make_uint2(0, 0);
-        uint32_t nv = 0;
-        if (sx >= 0 && sy >= 0 && sx < W && sy < H) {
+        // BANDS: staged row (o+1)*TY + r holds image row y0 + r + o*step; else staged row r holds y0 - step + r
+        const int sy = BANDS ? y0 + (row % TY) + (row / TY - 1) * step : y0 - step + row;
+        const int sx = x0 - step + c;
+        inside[k] = e < rows * cols && sx >= 0 && sy >= 0 && sx < W && sy < H;
+        cv[k] = make_float4(0, 0, 0, 0);
+        cvh[k] = pvh[k] = make_uint2(0, 0);
+        nvr[k] = 0;
+        if (inside[k]) {
             const size_t i = (size_t)sy * W + sx;
-            cv = colorF32 ? colorF32[i] : unpackHalf4(colorF16[i]);
-            pv = pos[i];
-            nv = normal[i];
+            if (colorF32) cv[k] = colorF32[i];
+            else cvh[k] = colorF16[i];
+            nvr[k] = normal[i];
+            pvh[k] = pos[i];
         }
-        sCol[e] = cv;
-        sPos[e] = pv;
-        sNrm[e] = nv;
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxTexels; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        if (e < rows * cols) {
+            float4 c = colorF32 ? cv[k] : unpackHalf4(cvh[k]);
+            if (c.x != c.x || c.y != c.y || c.z != c.z || c.w != c.w) c.x = __builtin_nanf("");
+            const uint32_t n = nvr[k];
+            sCol[e] = c;
+            sNrm[e] = make_float4(snorm8_to_float(n), snorm8_to_float(n >> 8), snorm8_to_float(n >> 16), snorm8_to_float(n >> 24));
+            sPos[e] = unpackHalf4(pvh[k]); // (a texel outside the image: zeros, like texelFetch on the oracle)
+        }
     }
     __syncthreads();
 
-    const int lx = threadIdx.x & (FT_X - 1), ly = threadIdx.x / FT_X;
+    const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
     const int x = x0 + lx, y = y0 + ly;
     if (x >= rect.x1 || y >= rect.y1) return;
 
-    const int centre = (4 + ly) * cols + step + lx;
+    const int rowStride = BANDS ? TY * cols : step * cols; // from a tap row to the next
+    const int centre = (BANDS ? TY + ly : ly + step) * cols + step + lx;
     const float4 cval = sCol[centre];
-    const float4 nval = unpackSnorm4(sNrm[centre]);
-    const float4 pval = unpackHalf4(sPos[centre]);
-    const float kern[3] = {1.0f / 16, 1.0f / 8, 1.0f / 4}; // filter.cpp:41-43 by |ox|+|oy|: 2→1/16, 1→1/8, 0→1/4
+    const float4 nval = sNrm[centre];
+    const float4 pval = sPos[centre];
     const float stepsq = (float)(step * step);
     const float r_c = 1.0f / c_phi, r_n = 1.0f / n_phi, r_p = 1.0f / p_phi, r_s = 1.0f / stepsq;
 
@@ -99,34 +128,47 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
     for (int oy = -1; oy <= 1; oy++) {
 #pragma unroll
         for (int ox = -1; ox <= 1; ox++) { // offsets in the order of filter.cpp:28-34
-            const int e = ((oy + 1) * 4 + ly) * cols + step + lx + ox * step;
+            const int e = centre + oy * rowStride + ox * step;
             const float4 ctmp = sCol[e];
-            if (ctmp.x != ctmp.x || ctmp.y != ctmp.y || ctmp.z != ctmp.z || ctmp.w != ctmp.w) continue;
-            float weight = 1.0f; // the centre tap: all three distances are 0 (or NaN, which the min below drops): weight 1
-            if (ox != 0 || oy != 0) {
+            if (ctmp.x != ctmp.x) continue; // atrous.fs:35-38 (a NaN in any channel: marked while staging)
+            // kernel weight by |ox|+|oy| (filter.cpp:41-43): 2 -> 1/16, 1 -> 1/8, 0 -> 1/4.  Powers of two, so
+            // (c * w) * k of the shader equals c * (w * k) bit for bit.
+            float wk = (ox != 0 && oy != 0) ? 1.0f / 16 : (ox != 0 || oy != 0) ? 1.0f / 8 : 1.0f / 4;
+            if (ox != 0 || oy != 0) { // (the centre tap: all three distances are 0, or NaN which the min drops: weight 1)
                 float4 t = sub4(cval, ctmp);
                 // c_w * n_w * p_w = min(exp(a),1) * min(exp(b),1) * min(exp(c),1) with a, b, c <= 0 (or NaN, for which
                 // the oracle's min returns 1): formed as ONE exp(a + b + c) with NaN arguments replaced by 0.  Same value up
                 // to the rounding of two products (about 1e-7 relative; the result is stored as fp16), a third of the
-                // transcendental work.
+                // transcendental work.  The exponential is the hardware's (v_exp_f32 on x * log2 e, about 2 ulp): the
+                // oracle platform's own exp is a polynomial that differs from libm's as much, and against its fixtures
+                // the fp16 outputs stay >= 99.9 % identical, the rest one fp16 step (scripts/filter_margin.py).
                 const float a = fminf(divUniform(-dot4(t, t), c_phi, r_c), 0.0f);
-                t = sub4(nval, unpackSnorm4(sNrm[e]));
-                const float dist2 = fmaxf(divUniform(dot4(t, t), stepsq, r_s), 0.0f);
+                const float4 n = sNrm[e];
+                const float dx = nval.x - n.x, dy = nval.y - n.y, dz = nval.z - n.z; // (w - w = 0 adds exactly nothing)
+                const float dist2 = fmaxf(divUniform(dx * dx + (dy * dy + dz * dz), stepsq, r_s), 0.0f);
                 const float b = fminf(divUniform(-dist2, n_phi, r_n), 0.0f);
-                t = sub4(pval, unpackHalf4(sPos[e]));
+                t = sub4(pval, sPos[e]);
                 const float c = fminf(divUniform(-dot4(t, t), p_phi, r_p), 0.0f);
-                weight = expf((a + b) + c);
+                wk *= __expf((a + b) + c);
             }
-            const float k = kern[2 - (ox != 0) - (oy != 0)];
-            sum.x += ctmp.x * weight * k;
-            sum.y += ctmp.y * weight * k;
-            sum.z += ctmp.z * weight * k;
-            sum.w += ctmp.w * weight * k;
-            cum_w += weight * k;
+            sum.x += ctmp.x * wk;
+            sum.y += ctmp.y * wk;
+            sum.z += ctmp.z * wk;
+            sum.w += ctmp.w * wk;
+            cum_w += wk;
         }
     }
-    out[(size_t)y * W + x] = make_uint2(pack_half2_rtz(sum.x / cum_w, sum.y / cum_w),
-                                        pack_half2_rtz(sum.z / cum_w, sum.w / cum_w));
+    // sum / cum_w (atrous.fs:52): four quotients by one divisor -> one reciprocal + the correction step of divUniform
+    // (the correctly rounded quotient for finite, non-zero cum_w; a pixel all of whose taps were skipped divides as written)
+    float4 q;
+    if (cum_w > 0.0f && cum_w < __builtin_inff()) {
+        const float r = 1.0f / cum_w;
+        q = make_float4(divUniform(sum.x, cum_w, r), divUniform(sum.y, cum_w, r), divUniform(sum.z, cum_w, r),
+                        divUniform(sum.w, cum_w, r));
+    } else {
+        q = make_float4(sum.x / cum_w, sum.y / cum_w, sum.z / cum_w, sum.w / cum_w);
+    }
+    out[(size_t)y * W + x] = make_uint2(pack_half2_rtz(q.x, q.y), pack_half2_rtz(q.z, q.w));
 }
 
 // quad.fs:10-22: mapped = 1 - exp(-hdr * exposure); pow(mapped, 1/2.2); alpha 1; 8-bit unorm store.
@@ -153,7 +195,6 @@ __global__ __launch_bounds__(256) void rt_tonemap_kernel(const float4 *__restric
     }
 }
 
-size_t rtAtrousLdsBytes(int step) { return (size_t)12 * (FT_X + 2 * step) * (16 + 8 + 4); }
 int rtAtrousMaxStep() { return FT_MAXSTEP; }
 
 hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const uint32_t *normal, const uint2 *pos,
@@ -161,9 +202,16 @@ hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const u
                           int step, hipStream_t stream) {
     const int rw = rect.x1 - rect.x0, rh = rect.y1 - rect.y0;
     if (rw <= 0 || rh <= 0) return hipSuccess;
-    const int tilesX = (rw + FT_X - 1) / FT_X, tilesY = (rh + FT_Y - 1) / FT_Y;
-    hipLaunchKernelGGL(rt_atrous_kernel, dim3(tilesX * tilesY), dim3(256), rtAtrousLdsBytes(step), stream, colorF32,
-                       colorF16, normal, pos, out, W, H, rect, tilesX, c_phi, n_phi, p_phi, step);
+    // tile shape by step width: the fewest staged texels per output pixel (48 bytes of LDS each)
+    auto launch = [&](auto kernel, int TX, int TY, bool bands) {
+        const int tilesX = (rw + TX - 1) / TX, tilesY = (rh + TY - 1) / TY;
+        const size_t ldsBytes = (size_t)(bands ? 3 * TY : TY + 2 * step) * (TX + 2 * step) * 48;
+        hipLaunchKernelGGL(kernel, dim3(tilesX * tilesY), dim3(256), ldsBytes, stream, colorF32, colorF16, normal, pos,
+                           out, W, H, rect, tilesX, c_phi, n_phi, p_phi, step);
+    };
+    if (step <= 2) launch(rt_atrous_kernel<16, 16, false>, 16, 16, false);
+    else if (step <= 4) launch(rt_atrous_kernel<32, 8, false>, 32, 8, false);
+    else launch(rt_atrous_kernel<256, 1, true>, 256, 1, true);
     return hipGetLastError();
 }
 
