@@ -240,6 +240,9 @@ def main():
     ap.add_argument("--cases", default=None,
                     help="extra cases in the same JSON line: comma list of room, lattice, config4, or none "
                          "(default: room,lattice at N = 1 with the default scene; config4 at N > 1)")
+    ap.add_argument("--rl", action="store_true",
+                    help="run the Q-table guided kernel (reference trace3.cs traceRL, dead in its main) instead of trace(): "
+                         "single GPU, no roofline / cpu_baseline (the table is shared mutable state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     if a.steps < 1:
@@ -340,6 +343,37 @@ def main():
         halo = hiplib.lib().rt_filter_halo(a.filter) if a.filter > 0 else 0
         gx, gy = parallel.tile_grid(W, H, world, halo)
         W, H = W * gx, H * gy
+    if a.rl:  # ---------------------------------------------- the Q-table guided kernel: a measurement of its own
+        if world != 1 or lattice:
+            sys.exit("--rl: single GPU, OBJ scenes only (the Q-table is shared mutable state and does not shard)")
+        wl = workloads.Workload(a.scene, W, H, with_qtable=True)
+        ctx.upload_scene(wl.buffers)
+        ctx.resize(W, H)
+        b = parallel.HipBackend(ctx, wl, a.spp, a.bounces, a.filter, device, kernel=hiplib.KERNEL_TRACE3_RL)
+        for _ in range(a.warmup):
+            b.trace((0, 0, W, H), 0)
+        ctx.sync()
+        ctx.reset_counters()
+        ctx.profile(True)
+        ctx.timings(reset=True)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            b.trace((0, 0, W, H), 0)
+            b.filter((0, 0, W, H))
+        ctx.sync()
+        el = time.perf_counter() - t0
+        cnt, tm = ctx.counters(), ctx.timings()
+        visits = ctx.download(10, np.int32, len(wl.buffers[10]) // 4)
+        print(json.dumps({"metric": f"Mrays/s (traceRL+filter), {a.scene}.obj {W}x{H} {a.spp}spp", "value": round(cnt.rays / el / 1e6, 3),
+                          "unit": "Mrays/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": round(el * 1e3 / a.steps, 4), "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "f32", "data": f"the reference's own {a.scene}.obj + its Q-table initialisation",
+                          "config": {"workload": f"{a.scene}.obj {W}x{H} {a.spp}spp maxBounces {a.bounces}, RT_KERNEL_TRACE3_RL "
+                                                 f"(Q-table guided, reference trace3.cs:695-791), {a.filter} filter iterations"},
+                          "rays_per_frame": cnt.rays / a.steps, "q_updates_total": int(visits.sum()),
+                          "kernel_ms_per_frame": {K.TIME_NAMES[i]: round(tm.ms[i] / a.steps, 4) for i in range(8) if tm.launches[i]}}))
+        return
     if lattice:
         nx, ny, nz = (int(v) for v in a.lattice.lower().split("x"))
         wl = workloads.LatticeWorkload(W, H, nx, ny, nz)

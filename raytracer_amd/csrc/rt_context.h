@@ -31,6 +31,8 @@ struct rt_ctx {
 
     // scene
     DevBuf boxes, leaves, tris48, tris128, mtls, emitters, raw[11], tables[5];
+    DevBuf cells;         // slots 7 + 8 as the Q-table kernel's cell search reads them (RtQTable::cells)
+    bool cellsStale = true;
     DevBuf spec;          // decision-tree table of the row-mode walk (RtScene::spec); hasSpec says whether it is valid
     bool hasSpec = false;
     int numNodes = 0, numTris = 0, numMtls = 0, numEmitters = 0;

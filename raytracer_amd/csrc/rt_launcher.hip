@@ -245,6 +245,7 @@ void rt_destroy(rt_ctx *c) {
     for (DevBuf &b : c->wfRay) releaseBuf(b);
     for (DevBuf *b : all) releaseBuf(*b);
     for (DevBuf &b : c->raw) releaseBuf(b);
+    releaseBuf(c->cells);
     for (DevBuf &b : c->tables) releaseBuf(b);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
@@ -381,6 +382,7 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
         c->numEmitters = (int)(nbytes / sizeof(RtTri128));
         return RT_OK;
     case RT_SLOT_VORONOI_NORMALS: case RT_SLOT_VORONOI_CENTRES: case RT_SLOT_QTABLE: case RT_SLOT_QVISITS:
+        if (slot == RT_SLOT_VORONOI_NORMALS || slot == RT_SLOT_VORONOI_CENTRES) c->cellsStale = true;
         return uploadTo(c, c->raw[slot], bytes, nbytes);
     default:
         return fail(c, RT_EINVAL, "rt_upload: unknown slot " + std::to_string(slot));
@@ -731,6 +733,14 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         q.numPoints = p->numPoints;
         q.maxTheta = p->maxTheta;
         q.maxPhi = p->maxPhi;
+        // the cells as the search reads them (normals normalised once, not once per visit): rebuilt when 7 or 8 change
+        if (c->cellsStale || !c->cells.p) {
+            if ((rc = ensure(c, c->cells, std::max<size_t>((size_t)q.numNormals, 1) * 32))) return rc;
+            hipError_t e = rtPrepareCells(q, (float4 *)c->cells.p, c->stream);
+            if (e != hipSuccess) return hipFail(c, e, "Q-table cell preparation");
+            c->cellsStale = false;
+        }
+        q.cells = (const float4 *)c->cells.p;
         for (int k = 0; k < n; ++k) { // the table is shared mutable state: one dispatch after the other
             SpanGuard span(c, TK_TRACE), span2(c, RT_TIME_PER_PIXEL);
             hipError_t e = rtLaunchTrace3RL(sc, q, img, params[k], r, (RtCountersDev *)c->counters.p, c->stream);

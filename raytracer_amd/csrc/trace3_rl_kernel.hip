@@ -7,14 +7,29 @@
 // Shared state.  Every path reads and updates one Q-table (Q[obj][cell][theta][phi] floats) and one visit
 // count per cell.  The reference does both without atomics from all invocations at once, so its frames depend
 // on the execution order and concurrent updates of a cell can be lost.  Here
-//   * the visit count is advanced with one atomic add, whose return value gives this update's
-//     alpha = 1 / (1 + visits);
-//   * Q <- (1 - alpha) Q + alpha u is applied with a compare-and-swap loop on the float's bits,
+//   * the visit count of a cell is advanced ONCE PER WAVE AND CELL: the lanes of a wave that update the same cell
+//     at the same bounce are grouped, the group's first lane adds the group's size with one atomic, and lane k of
+//     the group takes visits = returned value + k, i.e. alpha = 1 / (1 + visits) as if the group's updates had
+//     been applied one after the other in lane order;
+//   * Q <- (1 - alpha) Q + alpha u: the lanes of a wave that update the same entry are folded, in lane order, into
+//     one affine map Q <- A Q + B, which the group's first lane applies with a compare-and-swap loop on the
+//     float's bits (a lane on its own has A = 1 - alpha, B = alpha u: the reference's expression, bit for bit),
 // so every update is applied exactly once and a dispatch with a single path (the order-free case the parity
 // tests pin against the reference) evolves the table exactly as the reference does.  Vector atomics only.
+//
+// Measured on room.obj 1080p 4 spp (gpurun_out/rl_modes*.txt, profiles/): per-lane atomics 295 ms per frame;
+// grouped Q updates 163 ms (the compare-and-swap retries on hot entries were the largest single cost); grouped
+// visit counts: no further change; rows read 16 bytes per load + cells prepared once (rtPrepareCells) 150 ms.
+// Staging the cells of all objects in LDS (48 KB for room.obj) was measured twice and is slower than reading
+// them through L1 (440 vs 295 ms before, 198 vs 150 ms after the other changes), so it is not done.
 #include "trace3_device.h"
 
 #include "trace3_rl.h"
+
+#include <cstdlib>
+
+#define RL_MODE_GROUP_VISITS 1 // one visits atomic per wave and cell
+#define RL_MODE_GROUP_Q 2      // one Q compare-and-swap per wave and entry
 
 namespace {
 
@@ -28,14 +43,6 @@ __device__ __forceinline__ int f2i(float x) {
 __device__ __forceinline__ int wrapIndex(int i, unsigned stride, int count) {
     const unsigned off = (unsigned)i * stride, e = off / stride;
     return (e < (unsigned)count && off % stride == 0) ? (int)e : -1;
-}
-__device__ __forceinline__ f3 qNormal(const RtQTable &q, int i) {
-    i = wrapIndex(i, 16u, q.numNormals);
-    return i >= 0 ? xyz(q.normals[i]) : F3(0, 0, 0);
-}
-__device__ __forceinline__ f3 qCentre(const RtQTable &q, int i) {
-    i = wrapIndex(i, 16u, q.numCentres);
-    return i >= 0 ? xyz(q.centres[i]) : F3(0, 0, 0);
 }
 __device__ __forceinline__ float qRead(const RtQTable &q, int i) {
     i = wrapIndex(i, 4u, q.numQ);
@@ -61,29 +68,69 @@ __device__ __forceinline__ float fastacos(float x) { // qtablehelper.glsl:81-94
     ret = ret - (2 * negate) * ret;
     return negate * PI_F + ret;
 }
-// nearest_with_normal_space, qtablehelper.glsl:176-196
+// nearest_with_normal_space, qtablehelper.glsl:176-196, over the prepared cell table (rtPrepareCells): the stored
+// normal is already normalised (the reference normalises it at every visit), w says whether it was non-zero
+__device__ __forceinline__ void considerCell(const RtQTable &q, int e, int i, f3 pos, f3 nn, float &nearest, unsigned &nearestIdx) {
+    const float4 nv = q.cells[2 * e];
+    if (nv.w != 0.0f && dot(xyz(nv), nn) > 0.866f) {
+        const f3 d = xyz(q.cells[2 * e + 1]) - pos;
+        const float len = sqrtf(dot(d, d));
+        if (len < nearest) { nearestIdx = (unsigned)i; nearest = len; }
+    }
+}
 __device__ __forceinline__ unsigned findCell(const RtQTable &q, f3 pos, int objId, f3 normal) {
     float nearest = 10000.0f;
     unsigned nearestIdx = 0;
     const f3 nn = normalize(normal);
-    for (int i = 0; i < q.numPoints; ++i) {
-        const f3 nv = qNormal(q, objId * q.numPoints + i);
-        if (nv.x != 0.0f || nv.y != 0.0f || nv.z != 0.0f) {
-            if (dot(normalize(nv), nn) > 0.866f) {
-                const f3 d = qCentre(q, objId * q.numPoints + i) - pos;
-                const float len = sqrtf(dot(d, d));
-                if (len < nearest) { nearestIdx = (unsigned)i; nearest = len; }
-            }
+    const long long first = (long long)objId * q.numPoints;
+    if (objId >= 0 && first + q.numPoints <= (long long)q.numNormals) { // every cell of the object is in the table
+        // (one record at a time, the centre only when the normal passes: loading four records ahead was measured
+        //  slower, 180 vs 150 ms per room.obj frame — the loop is bound by L1 requests, not by their latency)
+        for (int i = 0; i < q.numPoints; ++i) considerCell(q, (int)first + i, i, pos, nn, nearest, nearestIdx);
+    } else { // the oracle platform's addressing: wrapped offsets, cells beyond the buffer read as zero (= skipped)
+        for (int i = 0; i < q.numPoints; ++i) {
+            const int e = wrapIndex(objId * q.numPoints + i, 16u, q.numNormals);
+            if (e >= 0) considerCell(q, e, i, pos, nn, nearest, nearestIdx);
         }
     }
     return nearestIdx;
 }
-__device__ __forceinline__ float maxQ(const RtQTable &q, unsigned idx, int objId) { // qtablehelper.glsl:212-224
-    float mq = 0;
-    const int base = q.numPoints * q.maxTheta * q.maxPhi * objId + q.maxTheta * q.maxPhi * (int)idx;
-    for (int i = 0; i < q.maxTheta; ++i)
-        for (int j = 0; j < q.maxPhi; ++j) mq = fmaxf(mq, qRead(q, base + i * q.maxPhi + j));
-    return mq;
+// One row of the table: the maxTheta * maxPhi entries of a cell, in the order the reference's loops read them.
+// Rows that lie inside the table and start on a 16-byte boundary are read four entries per load (buffer loads at
+// agent scope, like the single reads: they see the updates other compute units have made).
+typedef unsigned rl_v4u __attribute__((ext_vector_type(4)));
+struct QRow {
+    int base, len;
+    bool wide;
+};
+__device__ __forceinline__ QRow rowOf(const RtQTable &q, unsigned idx, int objId) {
+    QRow r;
+    r.len = q.maxTheta * q.maxPhi;
+    r.base = q.numPoints * r.len * objId + r.len * (int)idx;
+    r.wide = q.numQ <= 0x1FFFFFFF && r.base >= 0 && ((r.base | r.len) & 3) == 0 && r.base <= q.numQ - r.len;
+    return r;
+}
+__device__ __forceinline__ float4 qRead4(__amdgpu_buffer_rsrc_t rows, int i) {
+    const rl_v4u v = __builtin_amdgcn_raw_buffer_load_b128(rows, i * 4, 0, 16 /* sc1: agent scope */);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// max_q (qtablehelper.glsl:212-224) and, in the same pass, the row's sum as sampleCdf (:328-336) forms it
+__device__ __forceinline__ void rowMaxAndSum(const RtQTable &q, __amdgpu_buffer_rsrc_t rows, const QRow &r, float &mq, float &sum) {
+    mq = 0;
+    sum = 0;
+    if (r.wide) {
+        for (int i = 0; i < r.len; i += 4) {
+            const float4 v = qRead4(rows, r.base + i);
+            mq = fmaxf(fmaxf(fmaxf(fmaxf(mq, v.x), v.y), v.z), v.w);
+            sum = (((sum + v.x) + v.y) + v.z) + v.w;
+        }
+    } else {
+        for (int i = 0; i < r.len; ++i) {
+            const float v = qRead(q, r.base + i);
+            mq = fmaxf(mq, v);
+            sum += v;
+        }
+    }
 }
 __device__ __forceinline__ f3 orthogonal(f3 v) { // qtablehelper.glsl:231-235
     return fabsf(v.x) > fabsf(v.z) ? F3(-v.y, v.x, 0.0f) : F3(0.0f, -v.z, v.y);
@@ -100,69 +147,132 @@ __device__ __forceinline__ int findIndex(const RtQTable &q, unsigned idx, int ob
     const int base = q.numPoints * q.maxTheta * q.maxPhi * objId + q.maxTheta * q.maxPhi * (int)idx;
     return (int)((unsigned)base + (unsigned)u * (unsigned)q.maxPhi + (unsigned)v);
 }
-// updateQtable, qtablehelper.glsl:286-318
-__device__ __forceinline__ int updateQtable(const RtScene &sc, const RtQTable &q, const Surface &oSI, const Surface &hSI,
-                                            f3 dir, float lastAttenuation, int prevIdx, unsigned &updates) {
+// updateQtable, qtablehelper.glsl:286-318.
+// rowSum / rowSumValid: the sum of the hit cell's row as read for max_q, valid for the sampling that follows when
+// this path's own update lands in another row (what other paths do to the row in between is order-free anyway).
+__device__ __forceinline__ int updateQtable(const RtScene &sc, const RtQTable &q, __amdgpu_buffer_rsrc_t rows,
+                                            const Surface &oSI, const Surface &hSI, f3 dir, float lastAttenuation,
+                                            int prevIdx, unsigned &updates, int mode, float &rowSum, bool &rowSumValid) {
     const int oObj = objIdOf(sc, oSI.tridx), hObj = objIdOf(sc, hSI.tridx);
     const unsigned idxPrev = prevIdx >= 0 ? (unsigned)prevIdx : findCell(q, oSI.point, oObj, oSI.normal);
     const unsigned idxCurr = findCell(q, hSI.point, hObj, hSI.normal);
+    const int idxQ = findIndex(q, idxPrev, oObj, -dir, oSI.normal);
+    const int vi = wrapIndex(q.numPoints * oObj + (int)idxPrev, 4u, q.numVisits);
+    const int qi = wrapIndex(idxQ, 4u, q.numQ);
     float update;
+    rowSumValid = false;
     const RtMtl hm = fetchMtl(sc, hSI.matidx);
     if (hm.emitter) {
         const f3 ke = ld3(hm.Ke);
         update = fminf(fmaxf(sqrtf(dot(ke, ke)), 0.0f), 1.0f);
     } else {
-        update = lastAttenuation * maxQ(q, idxCurr, hObj);
+        const QRow r = rowOf(q, idxCurr, hObj);
+        float mq;
+        rowMaxAndSum(q, rows, r, mq, rowSum);
+        update = lastAttenuation * mq;
+        rowSumValid = r.wide && (qi < r.base || qi >= r.base + r.len);
     }
-    const int idxQ = findIndex(q, idxPrev, oObj, -dir, oSI.normal);
-    const int vi = wrapIndex(q.numPoints * oObj + (int)idxPrev, 4u, q.numVisits);
+    ++updates;
+    // visits[cell]++, one atomic per distinct cell of the wave: the lanes here are grouped by cell (no memory access
+    // inside the grouping loop), then the groups' first lanes add their group's size, all at once, and lane k of a
+    // group sees the count its k predecessors left
     int seen = 0;
-    if (vi >= 0) seen = atomicAdd(q.visits + vi, 1);
+    const int lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (mode & RL_MODE_GROUP_VISITS) {
+        unsigned long long todo = __ballot(vi >= 0), mine = 0;
+        while (todo) {
+            const int first = __ffsll((long long)todo) - 1;
+            const int cell = __shfl(vi, first, 64);
+            const unsigned long long group = __ballot(vi == cell) & todo;
+            if ((group >> lane) & 1ull) mine = group;
+            todo &= ~group;
+        }
+        const int leader = mine ? __ffsll((long long)mine) - 1 : lane;
+        int base = 0;
+        if (mine && lane == leader) base = atomicAdd(q.visits + vi, __popcll(mine));
+        base = __shfl(base, leader, 64);
+        seen = base + __popcll(mine & below);
+    } else if (vi >= 0) {
+        seen = atomicAdd(q.visits + vi, 1);
+    }
     const float alpha = 1.0f / (1.0f + (float)seen);
-    const int qi = wrapIndex(idxQ, 4u, q.numQ);
-    if (qi >= 0) {
+    float A = 1 - alpha, B = alpha * update;
+    bool apply = qi >= 0;
+    if (mode & RL_MODE_GROUP_Q) {
+        const bool had = apply;
+        unsigned long long todo = __ballot(had);
+        while (todo) {
+            const int first = __ffsll((long long)todo) - 1;
+            const int entry = __shfl(qi, first, 64);
+            unsigned long long group = __ballot(had && qi == entry) & todo;
+            todo &= ~group;
+            group &= group - 1; // the members after the first, folded into the first in lane order
+            while (group) {
+                const int k = __ffsll((long long)group) - 1;
+                const float ak = __shfl(alpha, k, 64), uk = __shfl(update, k, 64);
+                if (lane == first) {
+                    A = (1 - ak) * A;
+                    B = (1 - ak) * B + ak * uk;
+                }
+                if (lane == k) apply = false;
+                group &= group - 1;
+            }
+        }
+    }
+    if (apply) {
         unsigned *addr = (unsigned *)(q.qt + qi);
         unsigned old = __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (;;) {
-            const float nv = (1 - alpha) * __uint_as_float(old) + alpha * update;
+            const float nv = A * __uint_as_float(old) + B;
             const unsigned prev = atomicCAS(addr, old, __float_as_uint(nv));
             if (prev == old) break;
             old = prev;
         }
     }
-    ++updates;
     return (int)idxCurr;
 }
 // sampleScatteringDir (:399-419) with sampleCdf (:328-354), uniformSamplePatch (:378-389), aroundv (:362-369)
-__device__ __forceinline__ f3 sampleScatteringDir(const RtScene &sc, const RtQTable &q, const Surface &SI, int QIdx,
-                                                  f3 rnd3, float &outpdf) {
+__device__ __forceinline__ f3 sampleScatteringDir(const RtScene &sc, const RtQTable &q, __amdgpu_buffer_rsrc_t rows,
+                                                  const Surface &SI, int QIdx, f3 rnd3, bool haveSum, float rowSum,
+                                                  float &outpdf) {
     const int obj = objIdOf(sc, SI.tridx);
     const unsigned idx = QIdx >= 0 ? (unsigned)QIdx : findCell(q, SI.point, obj, SI.normal);
-    const int base = q.numPoints * q.maxPhi * q.maxTheta * obj + q.maxPhi * q.maxTheta * (int)idx;
-    float cdf = 0, den = 0, pdf = 0;
-    int pj = 0, pk = 0;
-    for (int j = 0; j < q.maxTheta; ++j)
-        for (int k = 0; k < q.maxPhi; ++k) den += qRead(q, base + j * q.maxPhi + k);
+    const QRow r = rowOf(q, idx, obj);
+    float cdf = 0, den = rowSum, pdf = 0;
+    if (!haveSum) {
+        float mq;
+        rowMaxAndSum(q, rows, r, mq, den);
+    }
+    int pick = 0, last = 0;
     bool done = false;
     float lastE = 0;
-    int lastJ = 0, lastK = 0;
-    for (int j = 0; j < q.maxTheta && !done; ++j)
-        for (int k = 0; k < q.maxPhi; ++k) {
-            const float e = qRead(q, base + j * q.maxPhi + k);
-            cdf += e;
-            if (e > 0) { lastE = e; lastJ = j; lastK = k; }
-            if (cdf / den >= rnd3.x) {
-                pdf = e / den;
-                pj = j; pk = k;
-                done = true;
-                break;
+    if (r.wide) {
+        for (int i = 0; i < r.len && !done; i += 4) {
+            const float4 v = qRead4(rows, r.base + i);
+            const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (done) continue;
+                const float e = e4[t];
+                cdf += e;
+                if (e > 0) { lastE = e; last = i + t; }
+                if (cdf / den >= rnd3.x) { pdf = e / den; pick = i + t; done = true; }
             }
         }
+    } else {
+        for (int i = 0; i < r.len; ++i) {
+            const float e = qRead(q, r.base + i);
+            cdf += e;
+            if (e > 0) { lastE = e; last = i; }
+            if (cdf / den >= rnd3.x) { pdf = e / den; pick = i; done = true; break; }
+        }
+    }
     // Running off the end is impossible when the two passes read the same values (cdf ends at den exactly); it
     // happens only when another path changed the row between the passes.  Take the last positive entry then,
     // so that a concurrent update cannot produce a zero pdf (and from it a non-finite Q value for everyone).
-    if (!done && den > 0 && lastE > 0) { pdf = lastE / den; pj = lastJ; pk = lastK; }
-    const int nu = pk, nv = pj;
+    if (!done && den > 0 && lastE > 0) { pdf = lastE / den; pick = last; }
+    const int nu = pick % q.maxPhi, nv = pick / q.maxPhi;
     const float u = ((float)nu + rnd3.y) / (float)q.maxPhi, v = ((float)nv + rnd3.z) / (float)q.maxTheta;
     const f3 d = F3(cosf(TWO_PI_F * v) * sqrtf(1 - u * u), sinf(TWO_PI_F * v) * sqrtf(1 - u * u), u);
     const f3 nvec = normalize(SI.normal), uvec = normalize(orthogonal(nvec)), vvec = normalize(cross(nvec, uvec));
@@ -171,7 +281,8 @@ __device__ __forceinline__ f3 sampleScatteringDir(const RtScene &sc, const RtQTa
 }
 
 __global__ __launch_bounds__(256) void rt_trace3_rl_kernel(RtScene sc, RtQTable q, RtImages img, rt_trace_params p,
-                                                           rt_rect tile, int tilesX, RtCountersDev *counters) {
+                                                           rt_rect tile, int tilesX, int mode, RtCountersDev *counters) {
+    const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(q.qt, 0, q.numQ <= 0x1FFFFFFF ? q.numQ * 4 : 0, 0x00020000);
     const int t = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lx = (lane & 7) + 8 * (wave & 1), ly = (lane >> 3) + 8 * (wave >> 1);
@@ -229,14 +340,17 @@ __global__ __launch_bounds__(256) void rt_trace3_rl_kernel(RtScene sc, RtQTable 
             } else {
                 L = L + beta * SKY;
             }
+            float rowSum = 0;
+            bool rowSumValid = false;
             if (bounces > 0)
-                prevQIdx = updateQtable(sc, q, prevSI, SI, dir, fmaxf(beta.x, fmaxf(beta.y, beta.z)), prevQIdx, updates);
+                prevQIdx = updateQtable(sc, q, rows, prevSI, SI, dir, fmaxf(beta.x, fmaxf(beta.y, beta.z)), prevQIdx, updates,
+                                        mode, rowSum, rowSumValid);
             if (!found || bounces >= p.maxBounces || isAreaLight) break;
 
             origin = SI.point + SI.normal * EPSILON_F;
             const f3 sample_rand = randvec3(c, bounces);
             float pdf;
-            const f3 wi = sampleScatteringDir(sc, q, SI, prevQIdx, sample_rand, pdf); // sampleOutDirRL, :609-616
+            const f3 wi = sampleScatteringDir(sc, q, rows, SI, prevQIdx, sample_rand, rowSumValid, rowSum, pdf); // sampleOutDirRL, :609-616
             const f3 f = brdfSpecular(m.Ns, wi, -dir, SI.normal) * SPECULARITY + brdfDiffuse(ld3(m.Kd)) * (1.0f - SPECULARITY);
             beta = beta * ((f * dot(normalize(SI.normal), normalize(wi))) / pdf);
             dir = wi;
@@ -271,13 +385,34 @@ __global__ __launch_bounds__(256) void rt_trace3_rl_kernel(RtScene sc, RtQTable 
     }
 }
 
+__global__ void rt_rl_prepare_cells_kernel(RtQTable q, float4 *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= q.numNormals) return;
+    const f3 nv = xyz(q.normals[i]);
+    const bool set = nv.x != 0.0f || nv.y != 0.0f || nv.z != 0.0f;
+    const f3 nn = set ? normalize(nv) : F3(0, 0, 0);
+    out[2 * i] = make_float4(nn.x, nn.y, nn.z, set ? 1.0f : 0.0f);
+    out[2 * i + 1] = i < q.numCentres ? q.centres[i] : make_float4(0, 0, 0, 0);
+}
+
 } // namespace
+
+hipError_t rtPrepareCells(const RtQTable &q, float4 *out, hipStream_t stream) {
+    if (q.numNormals <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_rl_prepare_cells_kernel, dim3((q.numNormals + 255) / 256), dim3(256), 0, stream, q, out);
+    return hipGetLastError();
+}
 
 hipError_t rtLaunchTrace3RL(const RtScene &sc, const RtQTable &q, const RtImages &img, const rt_trace_params &p,
                             const rt_rect &tile, RtCountersDev *counters, hipStream_t stream) {
     const int tw = tile.x1 - tile.x0, th = tile.y1 - tile.y0;
     if (tw <= 0 || th <= 0) return hipSuccess;
     const int tilesX = (tw + 15) / 16, tilesY = (th + 15) / 16;
-    hipLaunchKernelGGL(rt_trace3_rl_kernel, dim3(tilesX * tilesY), dim3(256), 0, stream, sc, q, img, p, tile, tilesX, counters);
+    static const int mode = [] {
+        const char *e = getenv("RT_RL_MODE"); // diagnostics: bit set of RL_MODE_*
+        return e ? atoi(e) : (RL_MODE_GROUP_VISITS | RL_MODE_GROUP_Q);
+    }();
+    hipLaunchKernelGGL(rt_trace3_rl_kernel, dim3(tilesX * tilesY), dim3(256), 0, stream, sc, q, img, p, tile, tilesX, mode,
+                       counters);
     return hipGetLastError();
 }

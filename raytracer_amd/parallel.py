@@ -69,18 +69,20 @@ def grow_rect(rect, halo, width, height):
 class HipBackend:
     """One hiplib.Context rendering a fixed workload (scene, camera, sample schedule)."""
 
-    def __init__(self, ctx, workload, spp, max_bounces, filter_iters, torch_device, flags=0, max_follows=1000):
+    def __init__(self, ctx, workload, spp, max_bounces, filter_iters, torch_device, flags=0, max_follows=1000,
+                 kernel=hiplib.KERNEL_TRACE3):
         self.ctx, self.wl = ctx, workload
         self.spp, self.max_bounces, self.filter_iters, self.flags = spp, max_bounces, filter_iters, flags
         self.max_follows = max_follows  # MAX_FOLLOWS of trace3.cs:214; lifted for scenes of millions of triangles
         self.device = torch_device
         self.halo = hiplib.lib().rt_filter_halo(filter_iters) if filter_iters > 0 else 0
         self.comm_ready = False
+        self.kernel = kernel  # KERNEL_TRACE3_RL: the Q-table guided kernel (one dispatch after the other: shared table)
 
     def trace(self, rect, frame=0):
         self.ctx.trace_samples(self.wl.rays, self.wl.eye, spp=self.spp, frame0=frame * self.spp,
                                max_bounces=self.max_bounces, flags=self.flags, rect=rect,
-                               num_emitters=self.wl.num_emitters, max_follows=self.max_follows)
+                               num_emitters=self.wl.num_emitters, max_follows=self.max_follows, kernel=self.kernel)
 
     def filter(self, rect):
         if self.filter_iters > 0:
