@@ -19,7 +19,10 @@
 //
 // Measured on room.obj 1080p 4 spp (gpurun_out/rl_modes*.txt, profiles/): per-lane atomics 295 ms per frame;
 // grouped Q updates 163 ms (the compare-and-swap retries on hot entries were the largest single cost); grouped
-// visit counts: no further change; rows read 16 bytes per load + cells prepared once (rtPrepareCells) 150 ms.
+// visit counts: no further change; rows read 16 bytes per load + cells prepared once (rtPrepareCells) 150 ms;
+// four row loads in flight 145 ms; the sampling pass reading one block of 16 instead of the row 135 ms.  With the
+// row reads removed altogether the frame takes 80 ms, with cached (not agent-scope) row loads 131 of 155 ms:
+// what is left is the latency of the scan's loads from L2 (waves spend 91 % of their cycles in s_waitcnt).
 // Staging the cells of all objects in LDS (48 KB for room.obj) was measured twice and is slower than reading
 // them through L1 (440 vs 295 ms before, 198 vs 150 ms after the other changes), so it is not done.
 #include "trace3_device.h"
@@ -114,16 +117,48 @@ __device__ __forceinline__ float4 qRead4(__amdgpu_buffer_rsrc_t rows, int i) {
     const rl_v4u v = __builtin_amdgcn_raw_buffer_load_b128(rows, i * 4, 0, 16 /* sc1: agent scope */);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-// max_q (qtablehelper.glsl:212-224) and, in the same pass, the row's sum as sampleCdf (:328-336) forms it
-__device__ __forceinline__ void rowMaxAndSum(const RtQTable &q, __amdgpu_buffer_rsrc_t rows, const QRow &r, float &mq, float &sum) {
-    mq = 0;
-    sum = 0;
+// max_q (qtablehelper.glsl:212-224) and, in the same pass, the row's sum as sampleCdf (:328-336) forms it.
+// The running sum IS sampleCdf's cdf (same additions in the same order), so its value after every 16 entries is
+// kept: the sampling that follows finds the block its random number falls in from these and reads 16 entries
+// again instead of the row (valid while no entry is negative or NaN: the running sum does not decrease then).
+#define RL_ROW_BLOCKS 8
+struct RowScan {
+    float mq, sum;
+    float after[RL_ROW_BLOCKS]; // the running sum after 16 (k + 1) entries
+    bool ordered;               // the row is wide, at most 16 RL_ROW_BLOCKS + 15 long and has no negative / NaN entry
+};
+__device__ __forceinline__ void scanRow(const RtQTable &q, __amdgpu_buffer_rsrc_t rows, const QRow &r, RowScan &o) {
+    float mq = 0, sum = 0, low = 0;
+    o.ordered = false;
+#pragma unroll
+    for (int k = 0; k < RL_ROW_BLOCKS; ++k) o.after[k] = 0;
     if (r.wide) {
-        for (int i = 0; i < r.len; i += 4) {
+        int i = 0;
+#pragma unroll
+        for (int k = 0; k < RL_ROW_BLOCKS; ++k) {
+            if (i + 16 <= r.len) { // four loads in flight
+                float4 v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[t] = qRead4(rows, r.base + i + 4 * t);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    mq = fmaxf(fmaxf(fmaxf(fmaxf(mq, v[t].x), v[t].y), v[t].z), v[t].w);
+                    low = fminf(fminf(fminf(fminf(low, v[t].x), v[t].y), v[t].z), v[t].w);
+                    sum = (((sum + v[t].x) + v[t].y) + v[t].z) + v[t].w;
+                }
+                o.after[k] = sum;
+                i += 16;
+            }
+        }
+        o.ordered = r.len - i < 16;
+        for (; i < r.len; i += 4) {
             const float4 v = qRead4(rows, r.base + i);
             mq = fmaxf(fmaxf(fmaxf(fmaxf(mq, v.x), v.y), v.z), v.w);
+            low = fminf(fminf(fminf(fminf(low, v.x), v.y), v.z), v.w);
             sum = (((sum + v.x) + v.y) + v.z) + v.w;
         }
+        // (fminf drops a NaN operand; a NaN entry makes the sum NaN, which the test below catches)
+        o.ordered = o.ordered && low >= 0.0f && sum > 0.0f && sum < 3.0e38f;
     } else {
         for (int i = 0; i < r.len; ++i) {
             const float v = qRead(q, r.base + i);
@@ -131,6 +166,8 @@ __device__ __forceinline__ void rowMaxAndSum(const RtQTable &q, __amdgpu_buffer_
             sum += v;
         }
     }
+    o.mq = mq;
+    o.sum = sum;
 }
 __device__ __forceinline__ f3 orthogonal(f3 v) { // qtablehelper.glsl:231-235
     return fabsf(v.x) > fabsf(v.z) ? F3(-v.y, v.x, 0.0f) : F3(0.0f, -v.z, v.y);
@@ -148,11 +185,11 @@ __device__ __forceinline__ int findIndex(const RtQTable &q, unsigned idx, int ob
     return (int)((unsigned)base + (unsigned)u * (unsigned)q.maxPhi + (unsigned)v);
 }
 // updateQtable, qtablehelper.glsl:286-318.
-// rowSum / rowSumValid: the sum of the hit cell's row as read for max_q, valid for the sampling that follows when
+// scan / scanValid: the hit cell's row as read for max_q, valid for the sampling that follows when
 // this path's own update lands in another row (what other paths do to the row in between is order-free anyway).
 __device__ __forceinline__ int updateQtable(const RtScene &sc, const RtQTable &q, __amdgpu_buffer_rsrc_t rows,
                                             const Surface &oSI, const Surface &hSI, f3 dir, float lastAttenuation,
-                                            int prevIdx, unsigned &updates, int mode, float &rowSum, bool &rowSumValid) {
+                                            int prevIdx, unsigned &updates, int mode, RowScan &scan, bool &scanValid) {
     const int oObj = objIdOf(sc, oSI.tridx), hObj = objIdOf(sc, hSI.tridx);
     const unsigned idxPrev = prevIdx >= 0 ? (unsigned)prevIdx : findCell(q, oSI.point, oObj, oSI.normal);
     const unsigned idxCurr = findCell(q, hSI.point, hObj, hSI.normal);
@@ -160,17 +197,16 @@ __device__ __forceinline__ int updateQtable(const RtScene &sc, const RtQTable &q
     const int vi = wrapIndex(q.numPoints * oObj + (int)idxPrev, 4u, q.numVisits);
     const int qi = wrapIndex(idxQ, 4u, q.numQ);
     float update;
-    rowSumValid = false;
+    scanValid = false;
     const RtMtl hm = fetchMtl(sc, hSI.matidx);
     if (hm.emitter) {
         const f3 ke = ld3(hm.Ke);
         update = fminf(fmaxf(sqrtf(dot(ke, ke)), 0.0f), 1.0f);
     } else {
         const QRow r = rowOf(q, idxCurr, hObj);
-        float mq;
-        rowMaxAndSum(q, rows, r, mq, rowSum);
-        update = lastAttenuation * mq;
-        rowSumValid = r.wide && (qi < r.base || qi >= r.base + r.len);
+        scanRow(q, rows, r, scan);
+        update = lastAttenuation * scan.mq;
+        scanValid = r.wide && (qi < r.base || qi >= r.base + r.len);
     }
     ++updates;
     // visits[cell]++, one atomic per distinct cell of the wave: the lanes here are grouped by cell (no memory access
@@ -234,20 +270,42 @@ __device__ __forceinline__ int updateQtable(const RtScene &sc, const RtQTable &q
 }
 // sampleScatteringDir (:399-419) with sampleCdf (:328-354), uniformSamplePatch (:378-389), aroundv (:362-369)
 __device__ __forceinline__ f3 sampleScatteringDir(const RtScene &sc, const RtQTable &q, __amdgpu_buffer_rsrc_t rows,
-                                                  const Surface &SI, int QIdx, f3 rnd3, bool haveSum, float rowSum,
+                                                  const Surface &SI, int QIdx, f3 rnd3, bool haveScan, RowScan &scan,
                                                   float &outpdf) {
     const int obj = objIdOf(sc, SI.tridx);
     const unsigned idx = QIdx >= 0 ? (unsigned)QIdx : findCell(q, SI.point, obj, SI.normal);
     const QRow r = rowOf(q, idx, obj);
-    float cdf = 0, den = rowSum, pdf = 0;
-    if (!haveSum) {
-        float mq;
-        rowMaxAndSum(q, rows, r, mq, den);
-    }
+    if (!haveScan) scanRow(q, rows, r, scan);
+    const float den = scan.sum;
+    float cdf = 0, pdf = 0;
     int pick = 0, last = 0;
     bool done = false;
     float lastE = 0;
-    if (r.wide) {
+    if (scan.ordered) { // the block of 16 the random number falls in, then that block entry by entry
+        int from = -1;
+#pragma unroll
+        for (int k = 0; k < RL_ROW_BLOCKS; ++k)
+            if (from < 0 && 16 * k + 16 <= r.len) {
+                if (scan.after[k] / den >= rnd3.x) from = 16 * k;
+                else cdf = scan.after[k];
+            }
+        if (from < 0) from = r.len & ~15;
+        float4 v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = from + 4 * t < r.len ? qRead4(rows, r.base + from + 4 * t) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float4 w = v[t / 4];
+            const float e = (t & 3) == 0 ? w.x : (t & 3) == 1 ? w.y : (t & 3) == 2 ? w.z : w.w;
+            if (!done && from + t < r.len) {
+                cdf += e;
+                if (cdf / den >= rnd3.x) { pdf = e / den; pick = from + t; done = true; }
+            }
+        }
+        // not found: another path changed the row since it was scanned; take the row from its start
+        if (!done) cdf = 0;
+    }
+    if (!done && r.wide) {
         for (int i = 0; i < r.len && !done; i += 4) {
             const float4 v = qRead4(rows, r.base + i);
             const float e4[4] = {v.x, v.y, v.z, v.w};
@@ -260,7 +318,7 @@ __device__ __forceinline__ f3 sampleScatteringDir(const RtScene &sc, const RtQTa
                 if (cdf / den >= rnd3.x) { pdf = e / den; pick = i + t; done = true; }
             }
         }
-    } else {
+    } else if (!done) {
         for (int i = 0; i < r.len; ++i) {
             const float e = qRead(q, r.base + i);
             cdf += e;
@@ -340,17 +398,17 @@ __global__ __launch_bounds__(256) void rt_trace3_rl_kernel(RtScene sc, RtQTable 
             } else {
                 L = L + beta * SKY;
             }
-            float rowSum = 0;
-            bool rowSumValid = false;
+            RowScan scan;
+            bool scanValid = false;
             if (bounces > 0)
                 prevQIdx = updateQtable(sc, q, rows, prevSI, SI, dir, fmaxf(beta.x, fmaxf(beta.y, beta.z)), prevQIdx, updates,
-                                        mode, rowSum, rowSumValid);
+                                        mode, scan, scanValid);
             if (!found || bounces >= p.maxBounces || isAreaLight) break;
 
             origin = SI.point + SI.normal * EPSILON_F;
             const f3 sample_rand = randvec3(c, bounces);
             float pdf;
-            const f3 wi = sampleScatteringDir(sc, q, rows, SI, prevQIdx, sample_rand, rowSumValid, rowSum, pdf); // sampleOutDirRL, :609-616
+            const f3 wi = sampleScatteringDir(sc, q, rows, SI, prevQIdx, sample_rand, scanValid, scan, pdf); // sampleOutDirRL, :609-616
             const f3 f = brdfSpecular(m.Ns, wi, -dir, SI.normal) * SPECULARITY + brdfDiffuse(ld3(m.Kd)) * (1.0f - SPECULARITY);
             beta = beta * ((f * dot(normalize(SI.normal), normalize(wi))) / pdf);
             dir = wi;
