@@ -92,7 +92,15 @@ enum rt_flags {
      * a ray through an edge or vertex shared by two triangles cannot slip between them.  Hit distances and
      * barycentrics differ from the reference's in the last bits, primary-hit ids only at such edges.  RT_KERNEL_TRACE3
      * only; not together with RT_FLAG_FAST_SHADOWS. */
-    RT_FLAG_WATERTIGHT = 32
+    RT_FLAG_WATERTIGHT = 32,
+    /* NOT what the reference runs; off by default.  randomEmitterSample (reference random.glsl:221-251) picks an
+     * emitter uniformly and keeps a power / distance weighted pick in a comment block (:223-248).  With this flag that
+     * block is what runs: emitter i is picked with probability proportional to |area vector| x |Ke| / squared distance
+     * when it faces the shaded point (for any number of emitters; the block's array holds 4).  Where the block is
+     * undefined: no emitter faces the point -> the uniform pick; rounding leaves the cumulative sum below the
+     * random number -> the last emitter of non-zero weight.  Same random numbers consumed as without the flag.
+     * RT_KERNEL_TRACE3 only. */
+    RT_FLAG_WEIGHTED_LIGHTS = 64
 };
 
 typedef struct rt_rect {

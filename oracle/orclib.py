@@ -23,7 +23,8 @@ class OrcTraceParams(ctypes.Structure):
                 ("time", ctypes.c_float), ("blend_factor", ctypes.c_float),
                 ("max_bounces", ctypes.c_int32), ("num_emitters", ctypes.c_int32),
                 ("max_follows", ctypes.c_int32), ("oob_seeds", ctypes.c_float * 3),
-                ("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32), ("y1", ctypes.c_int32)]
+                ("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32), ("y1", ctypes.c_int32),
+                ("weighted_lights", ctypes.c_int32)]
 
 
 class OrcAnalyticParams(ctypes.Structure):
@@ -106,8 +107,12 @@ class Scene:
                           self._keep[2].ctypes.data, sizes[2] // 32, self._keep[3].ctypes.data, sizes[3] // 128)
 
 
+def weighted_fallbacks(reset=True):
+    return int(lib().orc_weighted_fallbacks(int(reset)))
+
+
 def trace(scene, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.0625, max_bounces=5,
-          num_emitters=None, color=None, rect=None, max_follows=1000, oob='llvmpipe'):
+          num_emitters=None, color=None, rect=None, max_follows=1000, oob='llvmpipe', weighted_lights=False, light_pick_probe=False):
     """spp dispatches with time_k = time0 + dtime*k, blendFactor_k = k/(k+1) (as tests/golden fixtures)."""
     L = lib()
     n = width * height
@@ -125,6 +130,7 @@ def trace(scene, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.
     p.max_bounces = max_bounces
     p.num_emitters = scene.c.num_emitters if num_emitters is None else num_emitters
     p.max_follows = max_follows
+    p.weighted_lights = int(bool(weighted_lights)) | (2 if light_pick_probe else 0)
     if rect is not None:
         p.x0, p.y0, p.x1, p.y1 = rect
     stats_sum = np.zeros((height, width, 4), np.int64)

@@ -27,7 +27,7 @@ def run(scene_buffers, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dt
         num_emitters=0, importance=1, instrument=True, filter_iters=0, c_phi0=3.3, n_phi0=1e-2, p_phi0=5.5,
         repeat=1, init_color=None, init_normal=None, init_pos=None, stats_per_sample=False, timeout=3600,
         shader="trace3", phong_exponent=128.0, specular_factor=0.2, roughness=0.5, mis=1, use_blue_noise=1,
-        tables=None, seq=None):
+        tables=None, seq=None, weighted_lights=False, light_pick_probe=False):
     """scene_buffers: {slot: bytes} for slots 3..10 (missing → zeros). Returns dict of numpy arrays
     (row 0 = bottom image row, as GL) plus 'trace_ms' / 'filter_ms' lists and 'log'.
     shader: "trace3" (live kernel) | "trace" | "trace1" | "trace2"; tables: {"sobol"|"scramble"|"ranking"|"ltc1"|
@@ -46,7 +46,8 @@ def run(scene_buffers, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dt
                  f"p_phi0={_hexf(p_phi0)}", f"repeat={repeat}", f"out={tmp}/o",
                  f"dump_stats_per_sample={int(stats_per_sample)}", f"shader={shader}",
                  f"phong_exponent={_hexf(phong_exponent)}", f"specular_factor={_hexf(specular_factor)}",
-                 f"roughness={_hexf(roughness)}", f"mis={int(mis)}", f"use_blue_noise={int(use_blue_noise)}"]
+                 f"roughness={_hexf(roughness)}", f"mis={int(mis)}", f"use_blue_noise={int(use_blue_noise)}",
+                 f"weighted_lights={int(weighted_lights)}", f"light_pick_probe={int(light_pick_probe)}"]
         for name, b in (tables or {}).items():
             p = os.path.join(tmp, name + ".tbl")
             with open(p, "wb") as f:

@@ -10,6 +10,7 @@
 #include "rt_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -272,6 +273,7 @@ typedef struct {
     int seed;
     int max_follows;
     int num_emitters_uniform;
+    int weighted_lights; /* randomEmitterSample's commented-out block (random.glsl:223-248) instead of the uniform pick */
     float oob_seeds[3];
     /* instrumentation */
     int last_iterations;
@@ -469,14 +471,58 @@ static v3 EstimateDirect(ctx_t *c, v3 origin, v3 dir, const SI_t *SI, int bounce
     return Ld;
 }
 
-/* trace3.cs:574-582 with randomEmitterSample (random.glsl:221-251) */
+static int g_weighted_fallbacks; /* picks that took one of the two cases defined here (orc_weighted_fallbacks) */
+int32_t orc_weighted_fallbacks(int32_t reset) {
+    int v = g_weighted_fallbacks;
+    if (reset) g_weighted_fallbacks = 0;
+    return v;
+}
+/* The weight randomEmitterSample's commented-out block gives emitter i seen from `origin` (random.glsl:227-236):
+ * area-vector length x |Ke| / squared distance to v0 when the emitter faces the point, else 0. */
+static float emitterWeight(const ctx_t *c, int i, v3 origin) {
+    const tri_t *e = fetchEmitter(c, i);
+    v3 v0 = ld3(e->v0), v1 = ld3(e->v1), v2 = ld3(e->v2);
+    v3 d = vsub(v0, origin), e1 = vsub(v1, v0), e2 = vsub(v2, v0);
+    v3 n = cross3(e1, e2);
+    if (dot3(d, n) < 0) {
+        const mtl_t *m = fetchMtl(c, e->mtlIndex);
+        v3 ke = ld3(m->Ke);
+        return sqrtf(dot3(n, n)) * sqrtf(dot3(ke, ke)) / dot3(d, d);
+    }
+    return 0.0f;
+}
+/* trace3.cs:574-582 with randomEmitterSample (random.glsl:221-251).
+ * weighted_lights: the block the reference keeps commented out there (:223-248): emitters are picked with
+ * probability proportional to emitterWeight (no 4-entry limit on the weights array here).  Two cases the block
+ * leaves undefined are defined: when no emitter faces the point (total weight 0, or not finite) the live uniform
+ * pick is used; when rounding lets the cumulative sum end below `rand`, the last emitter of non-zero weight. */
 static v3 UniformSampleOneLight(ctx_t *c, v3 origin, v3 dir, const SI_t *SI, int bounces) {
     float light_rand = randfloat(c, bounces);
     const int ne = c->num_emitters_uniform;
     float light_prob = 1.0f / (float)ne;
     int li = (int)(light_rand * (float)ne);
     if (li > ne - 1) li = ne - 1;
+    if (c->weighted_lights & 1) {
+        float totalWeight = 0;
+        for (int i = 0; i < ne; i++) totalWeight += emitterWeight(c, i, origin);
+        if (totalWeight > 0 && totalWeight < INFINITY) {
+            float curWeight = 0, w = 0, lastW = 0;
+            int i, last = -1;
+            for (i = 0; i < ne; i++) {
+                w = emitterWeight(c, i, origin);
+                if (w > 0) { lastW = w; last = i; }
+                curWeight += w / totalWeight;
+                if (curWeight > light_rand) break;
+            }
+            if (i >= ne) { i = last; w = lastW; g_weighted_fallbacks++; }
+            li = i;
+            light_prob = w / totalWeight;
+        } else {
+            g_weighted_fallbacks++;
+        }
+    }
     const tri_t *light = fetchEmitter(c, li);
+    if (c->weighted_lights & 2) return V3(light_prob, (float)li, light_rand); /* the pick itself (see rt_oracle.h) */
     return vdivs(EstimateDirect(c, origin, dir, SI, bounces, light), light_prob);
 }
 
@@ -511,6 +557,7 @@ static void tracePath(ctx_t *c, v3 origin, v3 dir, v3 invdir, int maxBounces, pa
 
         origin = vadd(SI.point, vscale(SI.normal, EPSILON_F));
         v3 Ld = UniformSampleOneLight(c, origin, dir, &SI, bounces);
+        if (c->weighted_lights & 2) { L = Ld; break; } /* pick probe: the path's colour is the first pick */
         L = vadd(L, vmul(beta, Ld));
 
         float r0, r1, r2;
@@ -554,6 +601,7 @@ void orc_trace(const orc_scene *scene, const orc_trace_params *p, float *color, 
             c.seed = 0;
             c.max_follows = p->max_follows > 0 ? p->max_follows : 1000;
             c.num_emitters_uniform = p->num_emitters;
+            c.weighted_lights = p->weighted_lights;
             memcpy(c.oob_seeds, p->oob_seeds, sizeof c.oob_seeds);
             /* trace3.cs:805-807 */
             float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
@@ -810,6 +858,7 @@ void orc_trace_rl(const orc_scene *scene, orc_qtable *q, const orc_trace_params 
             c.time = p->time;
             c.max_follows = p->max_follows > 0 ? p->max_follows : 1000;
             c.num_emitters_uniform = p->num_emitters;
+            c.weighted_lights = p->weighted_lights;
             memcpy(c.oob_seeds, p->oob_seeds, sizeof c.oob_seeds);
             float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
             v3 dir = normalize3(mix3(mix3(r00, r01, pyf), mix3(r10, r11, pyf), pxf));

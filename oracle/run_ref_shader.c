@@ -355,6 +355,20 @@ int main(int argc, char **argv) {
                 src = replaceOnce(src, NULL, "texture2D(ltc_mat, uv)", "texture(ltc_mat, uv)");
                 src = replaceOnce(src, NULL, "texture2D(ltc_mag, uv)", "texture(ltc_mag, uv)");
             }
+            if (i == 2 && variant >= 3 && jobInt("weighted_lights", 0)) {
+                /* randomEmitterSample (random.glsl:221-251) keeps its power / distance weighted pick in a comment
+                 * block (:223-248) and returns a uniform pick; the block is enabled and its result returned */
+                const char *fn = "int randomEmitterSample(";
+                src = replaceOnce(src, fn, "/*float totalWeight = 0;", "float totalWeight = 0;");
+                src = replaceOnce(src, fn, "}*/", "}");
+                src = replaceOnce(src, fn, "//pdf = weights_[i]/totalWeight;", "pdf = weights_[i]/totalWeight; return i;");
+            }
+            if (i == 0 && variant == 3 && jobInt("light_pick_probe", 0)) {
+                /* pick probe: the path ends at its first light pick and returns (light_prob, li, light_rand) */
+                src = replaceOnce(src, "vec3 UniformSampleOneLight(", "return EstimateDirect(origin, dir, SI, bounces, light) / light_prob;",
+                                  "return vec3(light_prob, float(li), light_rand);");
+                src = replaceOnce(src, "vec3 trace(vec3 origin, vec3 dir, vec3 invdir)", "L += beta * Ld;", "return Ld;");
+            }
             if (i == 0 && variant == 4) {
                 /* the reference's main() calls trace(); its Q-table guided entry point is selected instead */
                 src = replaceOnce(src, "void main(void)", "vec3 color = trace(eye, dir, 1.0 / dir);",

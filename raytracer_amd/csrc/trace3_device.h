@@ -570,12 +570,52 @@ __device__ __forceinline__ f3 estimateDirectResolve(const f3 f1, float w1, float
     return Ld;
 }
 
-// UniformSampleOneLight's light pick, trace3.cs:574-582 + randomEmitterSample, random.glsl:221-251
-__device__ __forceinline__ int pickLight(PathCtx &c, int bounces, int numEmitters, float &light_prob) {
+// The weight randomEmitterSample's commented-out block (random.glsl:227-236) gives emitter i seen from `origin`:
+// length of the area vector x |Ke| / squared distance to v0 when the emitter faces the point, else 0.
+__device__ __forceinline__ float emitterWeight(const RtScene &sc, int i, f3 origin) {
+    f3 v0 = F3(0, 0, 0), v1 = v0, v2 = v0;
+    int mtl = 0;
+    if ((unsigned)i < (unsigned)sc.numEmitters) {
+        const RtTri128 *e = sc.emitters + i;
+        v0 = ld3(e->v0); v1 = ld3(e->v1); v2 = ld3(e->v2);
+        mtl = e->mtlIndex;
+    }
+    const f3 d = v0 - origin, n = cross(v1 - v0, v2 - v0);
+    if (dot(d, n) < 0.0f) {
+        const f3 ke = ld3(fetchMtl(sc, mtl).Ke);
+        return (sqrtf(dot(n, n)) * sqrtf(dot(ke, ke))) / dot(d, d);
+    }
+    return 0.0f;
+}
+// UniformSampleOneLight's light pick, trace3.cs:574-582 + randomEmitterSample, random.glsl:221-251.
+// weighted (RT_FLAG_WEIGHTED_LIGHTS): the block the reference keeps commented out there (:223-248), emitters
+// picked with probability proportional to emitterWeight, for any number of emitters (the block's array holds 4).
+// Two cases the block leaves undefined are defined here as in the oracle: no emitter faces the point (total weight
+// 0 or not finite) -> the uniform pick; the cumulative sum ends below the random number -> the last emitter of
+// non-zero weight.
+__device__ __forceinline__ int pickLight(const RtScene &sc, PathCtx &c, int bounces, int numEmitters, bool weighted,
+                                         f3 origin, float &light_prob) {
     const float light_rand = randfloat(c, bounces);
     light_prob = 1.0f / (float)numEmitters;
-    int li = (int)(light_rand * (float)numEmitters);
-    return min(li, numEmitters - 1);
+    int li = min((int)(light_rand * (float)numEmitters), numEmitters - 1);
+    if (weighted) {
+        float totalWeight = 0.0f;
+        for (int i = 0; i < numEmitters; ++i) totalWeight += emitterWeight(sc, i, origin);
+        if (totalWeight > 0.0f && totalWeight < INFINITY) {
+            float curWeight = 0.0f, w = 0.0f, lastW = 0.0f;
+            int i = 0, last = -1;
+            for (; i < numEmitters; ++i) {
+                w = emitterWeight(sc, i, origin);
+                if (w > 0.0f) { lastW = w; last = i; }
+                curWeight += w / totalWeight;
+                if (curWeight > light_rand) break;
+            }
+            if (i >= numEmitters) { i = last; w = lastW; }
+            li = i;
+            light_prob = w / totalWeight;
+        }
+    }
+    return li;
 }
 
 // The continuation of trace(), trace3.cs:654-684: new direction, beta update, Russian roulette.

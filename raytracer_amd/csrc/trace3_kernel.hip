@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
             origin = SI.point + SI.normal * EPSILON_F;
 
             float light_prob;
-            const int li = pickLight(c, bounces, p.numEmitters, light_prob);
+            const int li = pickLight(sc, c, bounces, p.numEmitters, (p.flags & RT_FLAG_WEIGHTED_LIGHTS) != 0, origin, light_prob);
             const LightTri light = loadLight(sc, li);
             DirectTerms T;
             estimateDirectPrepare(c, origin, dir, SI.normal, m, bounces, light, T);

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 const bool vis1 = fast ? h1 == WF_HIT_UNBLOCKED : sameTriangle(sc, h1, light);
                 const bool vis2 = fast ? h2 == WF_HIT_UNBLOCKED : sameTriangle(sc, h2, light);
                 const f3 Ke30 = ld3(fetchMtl(sc, light.mtlIndex).Ke) * 30.0f;
-                const float light_prob = 1.0f / (float)p.numEmitters;
+                const float light_prob = pd.w; // 1 / numEmitters, or the weighted pick's probability
                 const f3 Ld = estimateDirectResolve(F3(a1.x, a1.y, a1.z), a1.w, pd.x, conds & 1, F3(a2.x, a2.y, a2.z),
                                                     a2.w, pd.y, (conds >> 1) & 1, Ke30, vis1, vis2) / light_prob;
                 L = L + F3(bo.x, bo.y, bo.z) * Ld;
@@ -321,14 +321,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             float4 *outO = wf.rayO[(bounce + 1) & 1], *outD = wf.rayD[(bounce + 1) & 1];
             const f3 o2 = SI.point + SI.normal * EPSILON_F;
             float light_prob;
-            const int li = pickLight(c, bounce, p.numEmitters, light_prob);
+            const int li = pickLight(sc, c, bounce, p.numEmitters, (p.flags & RT_FLAG_WEIGHTED_LIGHTS) != 0, o2, light_prob);
             const LightTri light = loadLight(sc, li);
             {
                 DirectTerms T;
                 estimateDirectPrepare(c, o2, dir, SI.normal, m, bounce, light, T);
                 wf.f1w1[pid] = make_float4(T.f1.x, T.f1.y, T.f1.z, T.w1);
                 wf.f2w2[pid] = make_float4(T.f2.x, T.f2.y, T.f2.z, T.w2);
-                wf.pdfs[pid] = make_float4(T.lp1, T.bp2, __int_as_float(T.cond1 | (T.cond2 << 1)), 0.0f);
+                wf.pdfs[pid] = make_float4(T.lp1, T.bp2, __int_as_float(T.cond1 | (T.cond2 << 1)), light_prob);
                 float t1 = 0.0f, t2 = 0.0f, c1 = 1.0f, c2 = 1.0f;
                 if (p.flags & RT_FLAG_FAST_SHADOWS) { // rd.w = distance of the light; rays that miss it are not cast
                     t1 = lightDistance(light, o2, T.wi1);

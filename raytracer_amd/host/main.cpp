@@ -233,6 +233,7 @@ int main(int argc, char **argv) {
         else if (a == "--kernel") o.kernel = next();
         else if (a == "--watertight") o.launchFlags |= RT_FLAG_WATERTIGHT;      // opt-in variants, not the reference's algorithm
         else if (a == "--fast-shadows") o.launchFlags |= RT_FLAG_FAST_SHADOWS;
+        else if (a == "--weighted-lights") o.launchFlags |= RT_FLAG_WEIGHTED_LIGHTS;
         else if (a == "--max-follows") o.maxFollows = std::atoi(next());
         else if (a == "--reset-at") o.resetAt = std::atoi(next());
         else if (a == "--freeze-time") o.freezeTime = true;

@@ -67,6 +67,36 @@ class LatticeWorkload:
         return self.info.num_emitters
 
 
+class TwoLightsWorkload:
+    """A floor under two emissive quads of different size, height and power (4 emitter triangles: what the
+    weights array of the reference's commented-out emitter pick, random.glsl:224, can hold).  Every surface point
+    lies in front of at least one emitter, so that pick is defined everywhere (tests/golden/trace_twolights_*)."""
+
+    def __init__(self, width, height):
+        self.name, self.width, self.height = "twolights", width, height
+        self.scene = hostlib.Scene()
+        floor = np.zeros(2, hostlib.TRI_DTYPE)
+        a, b, c, d = (-2.0, 0.0, -2.0), (-2.0, 0.0, 2.0), (2.0, 0.0, 2.0), (2.0, 0.0, -2.0)
+        for k, (v0, v1, v2) in enumerate(((a, b, c), (a, c, d))):
+            floor[k]["v0"], floor[k]["v1"], floor[k]["v2"] = v0, v1, v2
+            floor[k]["n0"] = floor[k]["n1"] = floor[k]["n2"] = (0.0, 1.0, 0.0)
+        floor["mtlIndex"] = self.scene.add_material((0.75, 0.6, 0.45), 24.0, (0.0, 0.0, 0.0))
+        floor["objId"] = 0
+        self.scene.add_triangles(floor)
+        self.scene.add_quad_light((-0.8, 1.5, 0.0), 0.3, 0.3, (4.0, 3.5, 3.0))
+        self.scene.add_quad_light((1.0, 0.8, 0.3), 0.15, 0.2, (0.553949, 0.914877, 1.0))
+        self.scene.build(with_qtable=False)
+        self.info = self.scene.info()
+        self.camera = dict(eye=(0.0, 0.6, 2.5), look_at=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fov=60.0)
+        self.buffers = {s: self.scene.buffer(s) for s in (3, 4, 5, 6)}
+        self.rays = hostlib.camera_rays(width=width, height=height, **self.camera)
+        self.eye = np.array(self.camera["eye"], np.float32)
+
+    @property
+    def num_emitters(self):
+        return self.info.num_emitters
+
+
 # ---------------------------------------------------------------------------------------------
 # The analytic-scene kernels (reference trace.cs / trace1.cs / trace2.cs) have no scene buffers; their
 # inputs are the camera and, for trace1 / trace2, the reference's sample / look-up tables.

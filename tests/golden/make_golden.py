@@ -15,7 +15,9 @@ The fixtures are data (inputs + expected outputs); no reference source text is s
   * analytic_*.npz    : the reference's trace.cs / trace1.cs / trace2.cs on llvmpipe (trace1 / trace2 with the
     load-time portability patches listed in oracle/run_ref_shader.c).
   * rl_sequence_*.npz : trace3.cs with main() calling its traceRL entry point, one path per dispatch.
-usage: python tests/golden/make_golden.py [--only trace|ids|filter|kat|semantics|camera|analytic|rl]
+  * lights_*.npz      : trace3.cs with random.glsl's emitter pick, live (uniform) and with its commented-out
+    power / distance weighted block enabled at load time; radiance and the pick itself.
+usage: python tests/golden/make_golden.py [--only trace|ids|filter|kat|semantics|camera|analytic|rl|lights]
 """
 import argparse
 import hashlib
@@ -160,6 +162,30 @@ def gen_rl():
         print("wrote", path, os.path.getsize(path), "updates", int(r["qvisits"].sum()), "cells", visited.size)
 
 
+def gen_lights():
+    """The emitter pick of randomEmitterSample (random.glsl:221-251), uniform (live) and weighted (its commented-out
+    block, enabled at load time by run_ref_shader's weighted_lights=1): radiance frames, and the pick itself
+    (light_prob, emitter index, random number) of every pixel's first bounce through the light_pick_probe patch."""
+    w, h, spp, mb = 64, 48, 2, 3
+    wl = workloads.TwoLightsWorkload(w, h)
+    kw = dict(spp=spp, max_bounces=mb, num_emitters=wl.num_emitters)
+    arrays = {}
+    for tag, weighted in (("uniform", False), ("weighted", True)):
+        r = refrun.run(wl.buffers, w, h, wl.rays, wl.eye, weighted_lights=weighted, **kw)
+        arrays[f"color_{tag}"] = r["color"]
+        pr = refrun.run(wl.buffers, w, h, wl.rays, wl.eye, weighted_lights=weighted, light_pick_probe=True,
+                        spp=1, max_bounces=mb, num_emitters=wl.num_emitters)
+        arrays[f"pick_{tag}"] = pr["color"]
+        if not weighted:
+            arrays.update(tridx=r["tridx"], visits=r["visits"], normal=r["normal"], pos=r["pos"].view(np.uint16))
+    meta = dict(scene="twolights", width=w, height=h, spp=spp, max_bounces=mb, time0=1.25, dtime=0.0625,
+                num_emitters=wl.num_emitters, buffers_sha256=buffers_digest(wl))
+    path = os.path.join(OUT, f"lights_twolights_{w}x{h}_{spp}spp_mb{mb}.npz")
+    np.savez_compressed(path, rays=wl.rays, eye=wl.eye, meta=json.dumps(meta), **arrays)
+    differ = int((arrays["pick_uniform"].view(np.uint32) != arrays["pick_weighted"].view(np.uint32)).any(-1).sum())
+    print("wrote", path, os.path.getsize(path), "pixels whose pick differs between the two rules:", differ)
+
+
 def gen_filter():
     for name, w, h, spp, mb, iters in FILTER_CASES:
         wl = workloads.Workload(name, w, h)
@@ -290,7 +316,7 @@ def main():
     if not refrun.available():
         sys.exit("reference oracle unavailable: run `make ref` in the container that holds /root/reference")
     steps = dict(camera=gen_camera, semantics=gen_semantics, kat=gen_kat, trace=gen_trace, filter=gen_filter,
-                 ids=gen_ids, analytic=gen_analytic, rl=gen_rl)
+                 ids=gen_ids, analytic=gen_analytic, rl=gen_rl, lights=gen_lights)
     for k, fn in steps.items():
         if a.only in (None, k):
             fn()

@@ -360,6 +360,38 @@ class _CustomWorkload:
         self.num_emitters = self.info.num_emitters
 
 
+def test_weighted_lights_flag(ctx):
+    """RT_FLAG_WEIGHTED_LIGHTS: the emitter pick of the block the reference keeps commented out (random.glsl:223-248),
+    against the llvmpipe fixture made with that block enabled, against the oracle on scenes where the block's
+    undefined cases occur, and identical between the wavefront pipeline and the one-lane-per-path kernel."""
+    base = hiplib.FLAG_AUX | hiplib.FLAG_PIXEL_STATS
+    g = load_npz("lights_twolights_64x48_2spp_mb3.npz")
+    m = g["meta"]
+    wl = workloads.TwoLightsWorkload(m["width"], m["height"])
+    got = render(ctx, wl, m["spp"], m["max_bounces"], flags=base | hiplib.FLAG_WEIGHTED_LIGHTS)
+    assert_ids_equal(got, g)
+    assert_radiance_close(g["color_weighted"], got["color"], "twolights weighted vs llvmpipe")
+    plain = render(ctx, wl, m["spp"], m["max_bounces"], flags=base)
+    assert_radiance_close(g["color_uniform"], plain["color"], "twolights uniform vs llvmpipe")
+    assert not np.array_equal(plain["color"], got["color"])
+    for scene, w, h, spp, mb in (("room", 160, 120, 2, 5), ("scene", 192, 108, 3, 4)):
+        wl = workloads.Workload(scene, w, h)
+        ref = oracle_render(wl, spp, mb, weighted_lights=True)
+        results = []
+        for kw in (dict(), dict(batch=1), dict(batch=1, flags=base | hiplib.FLAG_WEIGHTED_LIGHTS | hiplib.FLAG_PER_PIXEL_KERNEL)):
+            kw.setdefault("flags", base | hiplib.FLAG_WEIGHTED_LIGHTS)
+            results.append(render(ctx, wl, spp, mb, **kw))
+        assert_ids_equal(results[0], ref)
+        assert_radiance_close(ref["color"], results[0]["color"], f"{scene} weighted vs oracle")
+        for other in results[1:]:
+            for k in other:
+                assert np.array_equal(other[k].view(np.uint8), results[0][k].view(np.uint8)), k
+    # the no-allocation entry point takes the flag too
+    if wl.width * wl.height * spp <= hiplib.lib().rt_static_max_paths():
+        st = render(ctx, wl, spp, mb, flags=base | hiplib.FLAG_WEIGHTED_LIGHTS, static=True)
+        assert np.array_equal(st["color"].view(np.uint8), results[0]["color"].view(np.uint8))
+
+
 def test_leaf_of_more_than_32_triangles_takes_the_general_node_path(ctx):
     """40 coincident triangles cannot be split, so the builder leaves them in one leaf (the reference's builder
     recurses forever on them, BVH.cpp:84-149).  A leaf of more than 32 triangles does not fit the packed node
