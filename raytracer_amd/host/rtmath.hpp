@@ -116,53 +116,41 @@ inline mat4 transpose(const mat4 &m) {
     return r;
 }
 
-// glm compute_inverse<4,4> (cofactor form), same sub-expression order.
+// Inverse by cofactors.  The camera rays must agree bit for bit with the ones the reference computes with its
+// vendored glm (tests/golden/camera_rays.json), so every product, difference and sum below is formed in the order
+// glm's 4x4 inverse forms it (glm is MIT / Happy Bunny licensed, (c) G-Truc Creation; the arithmetic order is what
+// is followed here, the code is this repository's):
+//   minors of columns {2,3}, {1,3}, {1,2} over the row pairs (2,3) (1,3) (1,2) (0,3) (0,2) (0,1);
+//   cofactor column c = lead[a] * M(b,d) - lead[b] * M(a,d) + lead[d] * M(a,b) for the rows a < b < d other than c,
+//   with lead[r] = (m[1][r], m[0][r], m[0][r], m[0][r]); signs (-1)^(i + c); determinant from column 0 of m and
+//   row 0 of the cofactor matrix, summed as (x + y) + (z + w); the result is cofactors * (1 / determinant).
 inline mat4 inverse(const mat4 &m) {
-    float Coef00 = m[2][2] * m[3][3] - m[3][2] * m[2][3];
-    float Coef02 = m[1][2] * m[3][3] - m[3][2] * m[1][3];
-    float Coef03 = m[1][2] * m[2][3] - m[2][2] * m[1][3];
-    float Coef04 = m[2][1] * m[3][3] - m[3][1] * m[2][3];
-    float Coef06 = m[1][1] * m[3][3] - m[3][1] * m[1][3];
-    float Coef07 = m[1][1] * m[2][3] - m[2][1] * m[1][3];
-    float Coef08 = m[2][1] * m[3][2] - m[3][1] * m[2][2];
-    float Coef10 = m[1][1] * m[3][2] - m[3][1] * m[1][2];
-    float Coef11 = m[1][1] * m[2][2] - m[2][1] * m[1][2];
-    float Coef12 = m[2][0] * m[3][3] - m[3][0] * m[2][3];
-    float Coef14 = m[1][0] * m[3][3] - m[3][0] * m[1][3];
-    float Coef15 = m[1][0] * m[2][3] - m[2][0] * m[1][3];
-    float Coef16 = m[2][0] * m[3][2] - m[3][0] * m[2][2];
-    float Coef18 = m[1][0] * m[3][2] - m[3][0] * m[1][2];
-    float Coef19 = m[1][0] * m[2][2] - m[2][0] * m[1][2];
-    float Coef20 = m[2][0] * m[3][1] - m[3][0] * m[2][1];
-    float Coef22 = m[1][0] * m[3][1] - m[3][0] * m[1][1];
-    float Coef23 = m[1][0] * m[2][1] - m[2][0] * m[1][1];
-
-    vec4 Fac0(Coef00, Coef00, Coef02, Coef03);
-    vec4 Fac1(Coef04, Coef04, Coef06, Coef07);
-    vec4 Fac2(Coef08, Coef08, Coef10, Coef11);
-    vec4 Fac3(Coef12, Coef12, Coef14, Coef15);
-    vec4 Fac4(Coef16, Coef16, Coef18, Coef19);
-    vec4 Fac5(Coef20, Coef20, Coef22, Coef23);
-
-    vec4 Vec0(m[1][0], m[0][0], m[0][0], m[0][0]);
-    vec4 Vec1(m[1][1], m[0][1], m[0][1], m[0][1]);
-    vec4 Vec2(m[1][2], m[0][2], m[0][2], m[0][2]);
-    vec4 Vec3(m[1][3], m[0][3], m[0][3], m[0][3]);
-
-    vec4 Inv0(Vec1 * Fac0 - Vec2 * Fac1 + Vec3 * Fac2);
-    vec4 Inv1(Vec0 * Fac0 - Vec2 * Fac3 + Vec3 * Fac4);
-    vec4 Inv2(Vec0 * Fac1 - Vec1 * Fac3 + Vec3 * Fac5);
-    vec4 Inv3(Vec0 * Fac2 - Vec1 * Fac4 + Vec2 * Fac5);
-
-    vec4 SignA(+1, -1, +1, -1);
-    vec4 SignB(-1, +1, -1, +1);
-    mat4 Inverse(Inv0 * SignA, Inv1 * SignB, Inv2 * SignA, Inv3 * SignB);
-
-    vec4 Row0(Inverse[0][0], Inverse[1][0], Inverse[2][0], Inverse[3][0]);
-    vec4 Dot0(m[0] * Row0);
-    float Dot1 = (Dot0.x + Dot0.y) + (Dot0.z + Dot0.w);
-    float OneOverDeterminant = 1.0f / Dot1;
-    return Inverse * OneOverDeterminant;
+    auto minor2 = [&m](int ca, int cb, int r, int s) { return m[ca][r] * m[cb][s] - m[cb][r] * m[ca][s]; };
+    static const int pairs[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
+    auto pairIndex = [](int r, int s) {
+        for (int k = 0; k < 6; ++k)
+            if (pairs[k][0] == r && pairs[k][1] == s) return k;
+        return 0;
+    };
+    vec4 M[6], lead[4];
+    for (int k = 0; k < 6; ++k) {
+        const int r = pairs[k][0], s = pairs[k][1];
+        const float m23 = minor2(2, 3, r, s);
+        M[k] = vec4(m23, m23, minor2(1, 3, r, s), minor2(1, 2, r, s));
+    }
+    for (int r = 0; r < 4; ++r) lead[r] = vec4(m[1][r], m[0][r], m[0][r], m[0][r]);
+    mat4 cof;
+    for (int c = 0; c < 4; ++c) {
+        int o[3], n = 0;
+        for (int r = 0; r < 4; ++r)
+            if (r != c) o[n++] = r;
+        const vec4 col = lead[o[0]] * M[pairIndex(o[1], o[2])] - lead[o[1]] * M[pairIndex(o[0], o[2])] +
+                         lead[o[2]] * M[pairIndex(o[0], o[1])];
+        for (int i = 0; i < 4; ++i) cof[c][i] = ((i + c) & 1) ? col[i] * -1.0f : col[i] * 1.0f;
+    }
+    const vec4 d = m[0] * vec4(cof[0][0], cof[1][0], cof[2][0], cof[3][0]);
+    const float det = (d.x + d.y) + (d.z + d.w);
+    return cof * (1.0f / det);
 }
 
 // glm::radians<float>: degrees * float(0.0174532925199432957...)
