@@ -83,7 +83,7 @@ def roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, root_mis
     kernels are bound by fp32 VALU issue (no FMA in parity mode: 78.6 Tops/s), their algorithmic bytes are served by
     LDS / L1 / L2 and `traffic` (measured HBM bytes) is orders of magnitude below them; beyond the L2s -> HBM."""
     names = K.TIME_NAMES
-    kernel_ms = {names[i]: tm.ms[i] for i in (1, 3, 4, 5, 6, 7) if tm.launches[i]}
+    kernel_ms = {names[i]: tm.ms[i] for i in (1, 3, 4, 5, 6, 7, 8) if tm.launches[i]}
     if not kernel_ms:
         return None
     dominant = max(kernel_ms, key=kernel_ms.get)
@@ -98,10 +98,16 @@ def roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, root_mis
     classified = float(root_misses) * steps
     ext_rays, ext_visits, ext_tests = cnt.rays - classified, cnt.node_visits - classified, float(cnt.tri_tests)
     ops = 0.0
-    if dominant == "wf_extend":    # reads a 32 B ray, writes a 16 B hit per ray
+    # (the stages that hold few rays run in rt_wf_extend_rows_kernel: timed and counted on their own)
+    if dominant in ("wf_extend", "wf_extend_rows"):    # reads a 32 B ray, writes a 16 B hit per ray
+        if dominant == "wf_extend_rows":
+            ext_rays, ext_visits, ext_tests = float(cnt.rows_rays), float(cnt.rows_node_visits), float(cnt.rows_tri_tests)
+        else:
+            ext_rays, ext_visits, ext_tests = (ext_rays - cnt.rows_rays, ext_visits - cnt.rows_node_visits,
+                                               ext_tests - cnt.rows_tri_tests)
         alg_bytes = 48.0 * (ext_visits + ext_tests) + 48.0 * ext_rays
         ops = 25.0 * ext_visits + 51.0 * ext_tests
-        kname = "rt_wf_extend_rows_kernel" if (resident and wl.info.num_nodes <= 896) else "rt_wf_extend_kernel"
+        kname = "rt_" + dominant + "_kernel"
     elif dominant == "per_pixel":
         alg_bytes = (48.0 * (cnt.node_visits + cnt.tri_tests) + 160.0 * cnt.shaded_hits + 28.0 * cnt.paths +
                      16.0 * cnt.paths * (spp - 1) / max(spp, 1))
@@ -204,7 +210,7 @@ def run_case(K, parallel, ctx, device, wl, scene_key, W, H, spp, bounces, filter
            "rays_past_root_per_frame": rays_per_frame - float(stop_at_root),
            "rays_per_frame_if_primary_per_sample": rays_per_frame + float((spp - 1) * W * H),
            "walk_stop": ctx.walk_stop(), "schedule_settle_frames": settle,
-           "kernel_ms_per_frame": {K.TIME_NAMES[i]: round(tm.ms[i] / steps, 4) for i in range(8) if tm.launches[i]},
+           "kernel_ms_per_frame": {K.TIME_NAMES[i]: round(tm.ms[i] / steps, 4) for i in range(len(K.TIME_NAMES)) if tm.launches[i]},
            "roofline": roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, stop_at_root)}
     if cpu_budget_s > 0:
         try:
@@ -372,7 +378,7 @@ def main():
                           "config": {"workload": f"{a.scene}.obj {W}x{H} {a.spp}spp maxBounces {a.bounces}, RT_KERNEL_TRACE3_RL "
                                                  f"(Q-table guided, reference trace3.cs:695-791), {a.filter} filter iterations"},
                           "rays_per_frame": cnt.rays / a.steps, "q_updates_total": int(visits.sum()),
-                          "kernel_ms_per_frame": {K.TIME_NAMES[i]: round(tm.ms[i] / a.steps, 4) for i in range(8) if tm.launches[i]}}))
+                          "kernel_ms_per_frame": {K.TIME_NAMES[i]: round(tm.ms[i] / a.steps, 4) for i in range(len(K.TIME_NAMES)) if tm.launches[i]}}))
         return
     if lattice:
         nx, ny, nz = (int(v) for v in a.lattice.lower().split("x"))
@@ -418,7 +424,7 @@ def main():
         fast_ms = (time.perf_counter() - t1) * 1e3 / max(1, a.steps // 2)
         backend.flags = 0
     local = torch.tensor([elapsed, float(cnt.rays), float(cnt.node_visits), float(cnt.tri_tests),
-                          float(cnt.shaded_hits), float(cnt.paths)] + [tm.ms[i] for i in range(8)] + [frame_rays],
+                          float(cnt.shaded_hits), float(cnt.paths)] + [tm.ms[i] for i in range(len(K.TIME_NAMES))] + [frame_rays],
                          dtype=torch.float64, device="cpu" if (rehearsal or dist is None) else device)
     if dist is not None:
         tmax = local.clone()
@@ -462,7 +468,7 @@ def main():
         return
 
     rays, visits, tests, hits, paths = sums[1:6]
-    frame_rays = sums[14]
+    frame_rays = sums[6 + len(K.TIME_NAMES)]
     ms_per_step = elapsed * 1e3 / a.steps
     mrays = frame_rays * a.steps / elapsed / 1e6
     rl = roofline(K, tm, cnt, wl, W, H, a.spp, a.filter, a.steps, scene_key, stop_at_root or 0)
@@ -489,7 +495,7 @@ def main():
         "node_visits_per_frame": visits / a.steps,
         "tri_tests_per_frame": tests / a.steps,
         "walk_stop": walk_stop, "schedule_settle_frames": settle,
-        "kernel_ms_per_frame_max_rank": {K.TIME_NAMES[i]: round(maxs[6 + i] / a.steps, 4) for i in range(8)
+        "kernel_ms_per_frame_max_rank": {K.TIME_NAMES[i]: round(maxs[6 + i] / a.steps, 4) for i in range(len(K.TIME_NAMES))
                                          if maxs[6 + i] > 0},
         "roofline": rl,
     }

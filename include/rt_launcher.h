@@ -135,6 +135,8 @@ typedef struct rt_counters {
     uint64_t paths;       /* pixel-samples (= primary rays)                                             */
     uint64_t primary_node_visits; /* the part of node_visits done by primary rays                      */
     uint64_t primary_tri_tests;   /* the part of tri_tests done by primary rays                        */
+    uint64_t rows_rays, rows_node_visits, rows_tri_tests; /* the part of rays / node_visits / tri_tests done by the
+                                                           * one-ray-per-16-lanes kernel (RT_TIME_WF_EXTEND_ROWS)     */
 } rt_counters;
 
 /* Accumulated device time per kernel family, measured with HIP events on the context's stream while
@@ -146,14 +148,16 @@ enum rt_time_kind {
     RT_TIME_TONEMAP = 2,
     RT_TIME_WF_PRIMARY = 3, /* ray generation + primary closest hit                           */
     RT_TIME_WF_LOGIC = 4,   /* shading / light sampling / queueing, one launch per bounce     */
-    RT_TIME_WF_EXTEND = 5,  /* persistent BVH traversal of the ray queue, one launch per bounce */
+    RT_TIME_WF_EXTEND = 5,  /* persistent BVH traversal of the ray queue (rt_wf_extend_kernel), one launch per stage
+                             * that is not run by RT_TIME_WF_EXTEND_ROWS                                */
     RT_TIME_WF_BLEND = 6,
     RT_TIME_PER_PIXEL = 7,  /* the one-lane-per-path kernel (RT_FLAG_PER_PIXEL_KERNEL)         */
-    RT_TIME_KINDS = 8
+    RT_TIME_WF_EXTEND_ROWS = 8, /* rt_wf_extend_rows_kernel: the stages with few rays, one ray per 16 lanes */
+    RT_TIME_KINDS = 9
 };
 typedef struct rt_timings {
-    double ms[8];
-    uint64_t launches[8];
+    double ms[RT_TIME_KINDS];
+    uint64_t launches[RT_TIME_KINDS];
 } rt_timings;
 
 enum rt_image {

@@ -67,6 +67,7 @@ struct rt_ctx {
     bool countsPending = false, havePrediction = false;
     int predictedCounts[32] = {};
     long long predictionKey = -1;       // tile / batch / bounces the prediction belongs to
+    long long pendingKey = -1;          // ... and the read-back in flight
     int lastWalkStop = 0;      // what the most recent wavefront launch used ...
     bool lastWalkSettled = false; // ... and whether that was a settled choice (rt_walk_stop)
     int tuneMinRays = 4;                             // RT_WF_MIN_RAYS: floor of the rays-per-wave rule

@@ -89,7 +89,8 @@ struct RtImages {
 #define RT_COUNTER_SHARDS 256
 struct __attribute__((aligned(128))) RtCountersDev {
     unsigned long long rays, node_visits, tri_tests, shaded_hits, paths, primary_visits, primary_tests;
-    unsigned long long pad[9];
+    unsigned long long rows_rays, rows_visits, rows_tests; // the part of rays / node_visits / tri_tests done by rt_wf_extend_rows_kernel
+    unsigned long long pad[6];
 };
 static_assert(sizeof(RtCountersDev) == 128, "one shard per 128-byte line");
 

@@ -631,6 +631,7 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         std::memcpy(c->predictedCounts, c->hostCounts, sizeof c->predictedCounts);
         c->countsPending = false;
         c->havePrediction = true;
+        c->predictionKey = c->pendingKey;
     }
     const int *predicted = (c->havePrediction && c->predictionKey == key) ? c->predictedCounts : nullptr;
     const bool profiled = c->profile && !noAlloc;
@@ -642,9 +643,9 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     if (e == hipSuccess && !c->countsPending) { // (one read-back in flight at a time: hostCounts is a single buffer)
         if (hipMemcpyAsync(c->hostCounts, wf.counts, 32 * sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
             hipEventRecord(c->countsEvent, c->stream) == hipSuccess) {
+            // (frames are queued faster than they finish: the newest sizes that HAVE arrived stay in use meanwhile)
             c->countsPending = true;
-            c->predictionKey = key;
-            c->havePrediction = false; // until this read-back has arrived
+            c->pendingKey = key;
         }
     }
     if (timeIt) {
@@ -1021,6 +1022,9 @@ int rt_counters_read(rt_ctx *c, rt_counters *out) {
         out->paths += s.paths;
         out->primary_node_visits += s.primary_visits;
         out->primary_tri_tests += s.primary_tests;
+        out->rows_rays += s.rows_rays;
+        out->rows_node_visits += s.rows_visits;
+        out->rows_tri_tests += s.rows_tests;
     }
     return RT_OK;
 }

@@ -988,9 +988,15 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
     c.visits = cVisits;
     c.tests = cTests;
     flushCounters(p, counters, c, 0u);
-    if (stage == 0 && !(p.flags & RT_FLAG_NO_COUNTERS)) {
-        waveAdd(&counterShard(counters)->primary_visits, cVisits);
-        waveAdd(&counterShard(counters)->primary_tests, cTests);
+    if (!(p.flags & RT_FLAG_NO_COUNTERS)) {
+        RtCountersDev *shard = counterShard(counters);
+        waveAdd(&shard->rows_rays, cRays);
+        waveAdd(&shard->rows_visits, cVisits);
+        waveAdd(&shard->rows_tests, cTests);
+        if (stage == 0) {
+            waveAdd(&shard->primary_visits, cVisits);
+            waveAdd(&shard->primary_tests, cTests);
+        }
     }
 }
 
@@ -1059,20 +1065,21 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     const size_t rowLds = (size_t)sc.numNodes * (32 + 2 * RT_SPEC_STRIDE);
     const int rowBlocks = 256; // one 16-wave block per CU (80 VGPRs: a second one would not be resident)
     auto extend = [&](int stage) {
-        if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, true);
         // rowMode 2: a stage that held few rays in the previous frame is bound by its longest walks, not by throughput
         bool rows = rowMode == 1;
         if (rowMode == 2 && predictedCounts) {
             const long long rays = (long long)predictedCounts[stage] * (stage == 0 ? 1 : 3);
             rows = rays > 0 && rays <= p.rowMaxRays;
         }
+        const int kind = rows ? RT_TIME_WF_EXTEND_ROWS : RT_TIME_WF_EXTEND;
+        if (prof) rtMarkKernel(prof, kind, true);
         if (rows)
             hipLaunchKernelGGL(rt_wf_extend_rows_kernel, dim3(rowBlocks), dim3(1024), rowLds, stream, sc, p, wf, stage,
                                counters);
         else
             hipLaunchKernelGGL(extendKernel, dim3(extendBlocks), dim3(256), extendLds, stream, scExtend, p, wf, stage,
                                p.refillLanes, counters);
-        if (prof) rtMarkKernel(prof, RT_TIME_WF_EXTEND, false);
+        if (prof) rtMarkKernel(prof, kind, false);
     };
     extend(0);
     for (int b = 0; b <= p.maxBounces; ++b) {

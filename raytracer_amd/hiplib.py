@@ -44,16 +44,17 @@ class TraceParams(ctypes.Structure):
 class Counters(ctypes.Structure):
     _fields_ = [("rays", ctypes.c_uint64), ("node_visits", ctypes.c_uint64), ("tri_tests", ctypes.c_uint64),
                 ("shaded_hits", ctypes.c_uint64), ("paths", ctypes.c_uint64),
-                ("primary_node_visits", ctypes.c_uint64), ("primary_tri_tests", ctypes.c_uint64)]
+                ("primary_node_visits", ctypes.c_uint64), ("primary_tri_tests", ctypes.c_uint64),
+                ("rows_rays", ctypes.c_uint64), ("rows_node_visits", ctypes.c_uint64), ("rows_tri_tests", ctypes.c_uint64)]
 
 
 (TIME_TRACE, TIME_FILTER, TIME_TONEMAP, TIME_WF_PRIMARY, TIME_WF_LOGIC, TIME_WF_EXTEND, TIME_WF_BLEND,
- TIME_PER_PIXEL) = range(8)
-TIME_NAMES = ["trace", "filter", "tonemap", "wf_primary", "wf_logic", "wf_extend", "wf_blend", "per_pixel"]
+ TIME_PER_PIXEL, TIME_WF_EXTEND_ROWS) = range(9)
+TIME_NAMES = ["trace", "filter", "tonemap", "wf_primary", "wf_logic", "wf_extend", "wf_blend", "per_pixel", "wf_extend_rows"]
 
 
 class Timings(ctypes.Structure):
-    _fields_ = [("ms", ctypes.c_double * 8), ("launches", ctypes.c_uint64 * 8)]
+    _fields_ = [("ms", ctypes.c_double * 9), ("launches", ctypes.c_uint64 * 9)]
 
     trace_ms = property(lambda s: s.ms[0])
     trace_launches = property(lambda s: s.launches[0])
