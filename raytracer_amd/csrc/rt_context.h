@@ -21,6 +21,7 @@ enum TimeKind { TK_TRACE = RT_TIME_TRACE, TK_FILTER = RT_TIME_FILTER, TK_TONEMAP
 struct TimedSpan {
     hipEvent_t start, stop;
     int kind;
+    bool stopShared = false; // the next span on the stream starts at this one's stop event (and returns it to the pool)
 };
 
 struct rt_ctx {
@@ -67,6 +68,8 @@ struct rt_ctx {
     bool countsPending = false, havePrediction = false;
     int predictedCounts[32] = {};
     long long predictionKey = -1;       // tile / batch / bounces the prediction belongs to
+    hipEvent_t chainEvent = nullptr;    // the stop event recorded last, if nothing was enqueued after it: the next
+    bool chainValid = false;            // span starts there instead of recording an event of its own (3 us each)
     long long pendingKey = -1;          // ... and the read-back in flight
     int lastWalkStop = 0;      // what the most recent wavefront launch used ...
     bool lastWalkSettled = false; // ... and whether that was a settled choice (rt_walk_stop)

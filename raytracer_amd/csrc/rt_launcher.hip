@@ -90,35 +90,57 @@ void foldFinishedSpans(rt_ctx *c) {
             c->accN[s.kind] += 1;
         }
         c->eventPool.push_back(s.start);
-        c->eventPool.push_back(s.stop);
+        if (!s.stopShared) c->eventPool.push_back(s.stop);
     }
     c->spans.erase(c->spans.begin(), c->spans.begin() + done);
+}
+
+// Start of a span on the context's stream: the stop event of the span that ended last when nothing has been
+// enqueued since (consecutive kernels of one call), else an event of its own.
+hipEvent_t spanStart(rt_ctx *c, bool mayChain) {
+    if (mayChain && c->chainValid && !c->spans.empty() && c->spans.back().stop == c->chainEvent) {
+        c->spans.back().stopShared = true;
+        c->chainValid = false;
+        return c->chainEvent;
+    }
+    c->chainValid = false;
+    hipEvent_t e = takeEvent(c);
+    (void)hipEventRecord(e, c->stream);
+    return e;
+}
+void spanStop(rt_ctx *c, TimedSpan &s) {
+    s.stop = takeEvent(c);
+    (void)hipEventRecord(s.stop, c->stream);
+    s.stopShared = false;
+    c->spans.push_back(s);
+    c->chainEvent = s.stop;
+    c->chainValid = true;
 }
 
 struct SpanGuard { // records start on construction, stop on end()
     rt_ctx *c;
     TimedSpan s;
     bool on;
+    // whole-call spans (TK_TRACE) enclose other spans and always record their own events
     SpanGuard(rt_ctx *c, int kind, bool enable = true) : c(c), on(c->profile && enable) {
         if (on) {
             s.kind = kind;
-            s.start = takeEvent(c);
-            s.stop = takeEvent(c);
-            (void)hipEventRecord(s.start, c->stream);
+            s.start = spanStart(c, kind != TK_TRACE);
         }
     }
     void end() {
         if (on) {
-            (void)hipEventRecord(s.stop, c->stream);
-            c->spans.push_back(s);
+            spanStop(c, s);
+            if (s.kind == TK_TRACE) c->chainValid = false; // (its stop is not the end of the kernel before it)
             on = false;
             if (c->spans.size() > 8192) foldFinishedSpans(c); // a caller that never reads the timings
         }
     }
-    ~SpanGuard() { // an early error return: the two events go back to the pool
+    ~SpanGuard() { // an early error return: the span is dropped; its start event stays with whoever shares it
         if (on) {
-            c->eventPool.push_back(s.start);
-            c->eventPool.push_back(s.stop);
+            if (c->spans.empty() || c->spans.back().stop != s.start) c->eventPool.push_back(s.start);
+            else c->spans.back().stopShared = false;
+            c->chainValid = false;
         }
     }
 };
@@ -131,12 +153,9 @@ void rtMarkKernel(void *opaque, int kind, bool begin) {
     static thread_local TimedSpan cur;
     if (begin) {
         cur.kind = kind;
-        cur.start = takeEvent(c);
-        cur.stop = takeEvent(c);
-        (void)hipEventRecord(cur.start, c->stream);
+        cur.start = spanStart(c, true);
     } else {
-        (void)hipEventRecord(cur.stop, c->stream);
-        c->spans.push_back(cur);
+        spanStop(c, cur);
     }
 }
 
@@ -1040,6 +1059,7 @@ int rt_counters_reset(rt_ctx *c) {
 int rt_profile(rt_ctx *c, int enable) {
     if (!c) return RT_EINVAL;
     c->profile = enable != 0;
+    c->chainValid = false;
     return RT_OK;
 }
 
