@@ -16,7 +16,7 @@ import csv, glob, sys, collections
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"].split("(")[0][-28:], r["Counter_Name"])
+        k = (r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").split("<")[0], r["Counter_Name"])
         agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
 for (k, c), (v, n) in sorted(agg.items()):
     if "rt_" in k:

@@ -12,7 +12,7 @@ tag, name = sys.argv[1], sys.argv[2]
 
 def kname(full):
     """'void rt_wf_extend_kernel<2>(RtScene, ...)' -> 'rt_wf_extend_kernel' (template variants are summed)."""
-    k = full.split("(")[0].strip()
+    k = full.replace("(anonymous namespace)::", "").split("(")[0].strip()
     if k.startswith("void "):
         k = k[5:]
     return k.split("<")[0]
