@@ -75,6 +75,18 @@ def cpu_baseline(wl, spp, max_bounces, filter_iters, max_follows=1000, budget_s=
                       f"traced {repeats}x in {t_trace:.2f} s each, {filter_iters} filter passes on the full frame in {t_filter:.2f} s"}
 
 
+class _GlooGather:
+    """torch.distributed.gather over a gloo group (host memory): the exchange bench.py falls back to when the
+    launcher's RCCL communicator cannot be set up."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.group = dist.new_group(backend="gloo")
+
+    def gather(self, tensor, gather_list=None, dst=0):
+        self.dist.gather(tensor, gather_list, dst=dst, group=self.group)
+
+
 def roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, root_misses=0):
     """Roofline of the kernel that took most device time, per launch, from HIP events recorded on the kernel's own
     stream (rt_profile).  Algorithmic work follows SURVEY.md 8(d): per traversal 25 ops + 48 B per node visit,
@@ -310,13 +322,29 @@ def main():
         ctx.upload_scene(wl.buffers)
         ctx.resize(W, H)
         backend = parallel.HipBackend(ctx, wl, spp, bounces, filt, device, max_follows=mf)
+        gather_group = dist
         if world > 1 and not rehearsal:
-            backend.init_comm(rank, world, dist)
+            # The launcher's own RCCL gather.  Should a rank fail to join (never seen; 8-GPU nodes are not ours to
+            # test on), every rank falls back to the blocking torch.distributed gather through host memory (a gloo
+            # group) rather than losing the run: same frame, slower exchange, and the JSON line says so.
+            ok = 1.0
+            try:
+                backend.init_comm(rank, world, dist)
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] rank {rank}: rt_comm_init failed: {e}", file=sys.stderr)
+                ok = 0.0
+            agree = torch.tensor([ok], device=device)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if float(agree[0]) == 0.0:
+                if backend.comm_ready:
+                    ctx.comm_destroy()
+                    backend.comm_ready = False
+                gather_group = _GlooGather(dist)
         frame = parallel.TiledFrame(backend, W, H, rank, world, hiplib.IMAGE_FILTERED if filt else hiplib.IMAGE_COLOR)
 
         def step():
             frame.render(0)
-            frame.gather(dist)
+            frame.gather(gather_group)
 
         settle = 0
         while settle < 6:  # set-up: let the launcher settle its schedule (it times two candidates on the first frames)
@@ -490,7 +518,8 @@ def main():
                    "parallelism": f"{world} ranks as a {frame.grid[0]} x {frame.grid[1]} grid of screen-space tiles"
                                   + (f" of {tileW}x{tileH} (the frame grows with N)" if world > 1 and a.scaling == "weak" else "")
                                   + f", halo {backend.halo} px, one gather to rank 0"
-                                  + (" (rt_gather_tiles: RCCL send/recv on a second stream, event-ordered)" if frame.native else "")},
+                                  + (" (rt_gather_tiles: RCCL send/recv on a second stream, event-ordered)" if frame.native else
+                                     " (torch.distributed gather through host memory)" if world > 1 else "")},
         "rays_per_frame": frame_rays, "rays_traced_per_frame_incl_halo": rays / a.steps,
         "node_visits_per_frame": visits / a.steps,
         "tri_tests_per_frame": tests / a.steps,

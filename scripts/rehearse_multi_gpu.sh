@@ -7,11 +7,11 @@ N=${1:-2}
 REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$REPO"
 export RT_BENCH_COLLECTIVES=gloo RT_BENCH_CHECKSUM=1 MASTER_ADDR=127.0.0.1
-python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/rehearse_1.json
+python bench.py --steps 3 --warmup 1 --no-cpu-baseline --cases none > gpurun_out/rehearse_1.json
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port 29517 \
-    bench.py --gpus "$N" --steps 3 --warmup 1 --scaling strong > gpurun_out/rehearse_$N.json
+    bench.py --gpus "$N" --steps 3 --warmup 1 --scaling strong --cases none > gpurun_out/rehearse_$N.json
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port 29518 \
-    bench.py --gpus "$N" --steps 3 --warmup 1 > gpurun_out/rehearse_weak_$N.json
+    bench.py --gpus "$N" --steps 3 --warmup 1 --scaling weak --cases none > gpurun_out/rehearse_weak_$N.json
 python - "$N" <<'PY'
 import json, sys
 n = sys.argv[1]
