@@ -72,9 +72,10 @@ int drainSpans(rt_ctx *c) {
         c->accMs[s.kind] += ms;
         c->accN[s.kind] += 1;
         c->eventPool.push_back(s.start);
-        c->eventPool.push_back(s.stop);
+        if (!s.stopShared) c->eventPool.push_back(s.stop); // (a shared stop goes back as the next span's start)
     }
     c->spans.clear();
+    c->chainValid = false;
     return RT_OK;
 }
 
