@@ -68,6 +68,12 @@ struct rt_ctx {
     bool countsPending = false, havePrediction = false;
     int predictedCounts[32] = {};
     long long predictionKey = -1;       // tile / batch / bounces the prediction belongs to
+    // rt_filter: pass 0 runs on `stream` and leaves a private copy of the normals / positions it read; the later passes
+    // run on filterStream from that copy, so the next frame's trace (which rewrites the G-buffer) does not wait for them
+    hipStream_t filterStream = nullptr;
+    hipEvent_t filterFed = nullptr, filterDone = nullptr; // pass 0 finished (on stream); last pass finished (on filterStream)
+    bool filterPending = false;                            // filterDone has been recorded and not yet been waited for
+    DevBuf normalCopy, posCopy;
     hipEvent_t chainEvent = nullptr;    // the stop event recorded last, if nothing was enqueued after it: the next
     bool chainValid = false;            // span starts there instead of recording an event of its own (3 us each)
     long long pendingKey = -1;          // ... and the read-back in flight
@@ -192,5 +198,8 @@ inline ImageRef imageOf(rt_ctx *c, int image) {
     }
 }
 
+
+// rt_launcher.hip: orders the context's stream after the filter passes still running on filterStream (no host wait)
+int rtJoinFilter(rt_ctx *c);
 
 #endif

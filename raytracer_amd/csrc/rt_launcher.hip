@@ -24,8 +24,8 @@ hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace
 struct rt_ctx;
 void rtMarkKernel(void *ctxOpaque, int kind, bool begin);
 hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const uint32_t *normal, const uint2 *pos,
-                          uint2 *out, int W, int H, const rt_rect &rect, float c_phi, float n_phi, float p_phi,
-                          int step, hipStream_t stream);
+                          uint2 *out, uint32_t *normalCopy, uint2 *posCopy, int W, int H, const rt_rect &rect, float c_phi,
+                          float n_phi, float p_phi, int step, hipStream_t stream);
 hipError_t rtLaunchTonemap(const float4 *colorF32, const uint2 *colorF16, uint32_t *out, int W, const rt_rect &rect,
                            float exposure, hipStream_t stream);
 int rtAtrousMaxStep();
@@ -98,7 +98,12 @@ void foldFinishedSpans(rt_ctx *c) {
 
 // Start of a span on the context's stream: the stop event of the span that ended last when nothing has been
 // enqueued since (consecutive kernels of one call), else an event of its own.
-hipEvent_t spanStart(rt_ctx *c, bool mayChain) {
+hipEvent_t spanStart(rt_ctx *c, bool mayChain, hipStream_t stream = nullptr) {
+    if (stream && stream != c->stream) { // a span on the context's second stream: events of its own
+        hipEvent_t e = takeEvent(c);
+        (void)hipEventRecord(e, stream);
+        return e;
+    }
     if (mayChain && c->chainValid && !c->spans.empty() && c->spans.back().stop == c->chainEvent) {
         c->spans.back().stopShared = true;
         c->chainValid = false;
@@ -109,29 +114,47 @@ hipEvent_t spanStart(rt_ctx *c, bool mayChain) {
     (void)hipEventRecord(e, c->stream);
     return e;
 }
-void spanStop(rt_ctx *c, TimedSpan &s) {
+void spanStop(rt_ctx *c, TimedSpan &s, hipStream_t stream = nullptr) {
+    const bool other = stream && stream != c->stream;
     s.stop = takeEvent(c);
-    (void)hipEventRecord(s.stop, c->stream);
+    (void)hipEventRecord(s.stop, other ? stream : c->stream);
     s.stopShared = false;
     c->spans.push_back(s);
-    c->chainEvent = s.stop;
-    c->chainValid = true;
+    if (!other) {
+        c->chainEvent = s.stop;
+        c->chainValid = true;
+    }
 }
+
+// Whatever reads or rewrites what the filter's later passes use (the filtered images, the G-buffer copy) is ordered
+// after them: the context's stream waits for the event of the last pass (no host wait).
+int joinFilter(rt_ctx *c) { return rtJoinFilter(c); }
+} // namespace
+int rtJoinFilter(rt_ctx *c) {
+    if (c->filterPending) {
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->filterDone, 0));
+        c->filterPending = false;
+    }
+    return RT_OK;
+}
+namespace {
 
 struct SpanGuard { // records start on construction, stop on end()
     rt_ctx *c;
     TimedSpan s;
     bool on;
     // whole-call spans (TK_TRACE) enclose other spans and always record their own events
-    SpanGuard(rt_ctx *c, int kind, bool enable = true) : c(c), on(c->profile && enable) {
+    hipStream_t stream;
+    SpanGuard(rt_ctx *c, int kind, bool enable = true, hipStream_t stream = nullptr)
+        : c(c), on(c->profile && enable), stream(stream) {
         if (on) {
             s.kind = kind;
-            s.start = spanStart(c, kind != TK_TRACE);
+            s.start = spanStart(c, kind != TK_TRACE, stream);
         }
     }
     void end() {
         if (on) {
-            spanStop(c, s);
+            spanStop(c, s, stream);
             if (s.kind == TK_TRACE) c->chainValid = false; // (its stop is not the end of the kernel before it)
             on = false;
             if (c->spans.size() > 8192) foldFinishedSpans(c); // a caller that never reads the timings
@@ -186,6 +209,14 @@ size_t rt_image_pixel_bytes(int image) {
     }
 }
 
+// The later filter passes fill the SIMDs the next frame's sparse trace stages leave idle; the trace is the critical
+// path, so their stream gets the lowest priority the device offers.
+static bool createFilterStream(rt_ctx *c) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    return hipStreamCreateWithPriority(&c->filterStream, hipStreamNonBlocking, least) == hipSuccess;
+}
+
 int rt_create(int device_id, rt_ctx **out) {
     if (!out) return RT_EINVAL;
     *out = nullptr;
@@ -212,7 +243,10 @@ int rt_create(int device_id, rt_ctx **out) {
         rtStaticScratchPtr[device_id] = ptr;
     }
     if (hipHostMalloc((void **)&c->hostCounts, 32 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&c->countsEvent, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->countsEvent, hipEventDisableTiming) != hipSuccess ||
+        !createFilterStream(c) ||
+        hipEventCreateWithFlags(&c->filterFed, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->filterDone, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(c->ownStream);
         delete c;
         return RT_ENOMEM;
@@ -248,7 +282,13 @@ void rt_destroy(rt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->filterStream) (void)hipStreamSynchronize(c->filterStream);
     rtCommRelease(c);
+    if (c->filterFed) (void)hipEventDestroy(c->filterFed);
+    if (c->filterDone) (void)hipEventDestroy(c->filterDone);
+    if (c->filterStream) (void)hipStreamDestroy(c->filterStream);
+    releaseBuf(c->normalCopy);
+    releaseBuf(c->posCopy);
     if (c->countsEvent) (void)hipEventDestroy(c->countsEvent);
     if (c->hostCounts) (void)hipHostFree(c->hostCounts);
     for (TimedSpan &s : c->spans) {
@@ -278,6 +318,9 @@ int rt_set_stream(rt_ctx *c, void *hip_stream) {
     int r = bind(c);
     if (r) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->filterStream));
+    c->filterPending = false;
+    c->chainValid = false;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
     return RT_OK;
 }
@@ -439,6 +482,7 @@ int rt_clear(rt_ctx *c) {
     int r = bind(c);
     if (r) return r;
     const size_t n = (size_t)c->width * c->height;
+    if ((r = rtJoinFilter(c))) return r;
     HIP_TRY(c, hipMemsetAsync(c->color.p, 0, n * 16, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->normal.p, 0, n * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->pos.p, 0, n * 8, c->stream));
@@ -459,9 +503,12 @@ int rt_resize(rt_ctx *c, int width, int height) {
     int r = bind(c);
     if (r) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->filterStream));
+    c->filterPending = false;
     rtCommQuiesce(c);
     if (width != c->width || height != c->height) c->assembledPixelBytes = 0; // the assembled frame belongs to the old size
     const size_t n = (size_t)width * height;
+    if ((r = ensure(c, c->normalCopy, n * 4)) || (r = ensure(c, c->posCopy, n * 8))) return r;
     if ((r = ensure(c, c->color, n * 16)) || (r = ensure(c, c->normal, n * 4)) || (r = ensure(c, c->pos, n * 8)) ||
         (r = ensure(c, c->filt[0], n * 8)) || (r = ensure(c, c->filt[1], n * 8)) || (r = ensure(c, c->tridx, n * 4)) ||
         (r = ensure(c, c->visits, n * 4)) || (r = ensure(c, c->stats, n * 16)) || (r = ensure(c, c->ldr, n * 4)))
@@ -907,7 +954,11 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
         return fail(c, RT_EINVAL, "rt_filter: step width beyond the LDS tile limit (iterations <= 6)");
     int rc = bind(c);
     if (rc) return rc;
-    // Filter::filter, reference src/filter.cpp:68-104
+    // Filter::filter, reference src/filter.cpp:68-104.  Pass 0 runs on the context's stream and leaves a copy of the
+    // normals / positions of the pixels it filtered; the later passes run on filterStream and read that copy, so the
+    // next frame's trace may rewrite the G-buffer while they run.  Whoever touches the filtered images or starts
+    // another filter is ordered after them by joinFilter (an event wait on the stream, never on the host).
+    if ((rc = joinFilter(c))) return rc;
     const float4 *readF32 = (const float4 *)c->color.p;
     const uint2 *readF16 = nullptr;
     int write = 0;
@@ -924,16 +975,30 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
         r.y0 = target.y0 - grow < 0 ? 0 : target.y0 - grow;
         r.x1 = target.x1 + grow > c->width ? c->width : target.x1 + grow;
         r.y1 = target.y1 + grow > c->height ? c->height : target.y1 + grow;
-        SpanGuard span(c, TK_FILTER);
-        hipError_t e = rtLaunchAtrous(readF32, readF16, (const uint32_t *)c->normal.p, (const uint2 *)c->pos.p,
-                                      (uint2 *)c->filt[write].p, c->width, c->height, r, c_phi, n_phi, p_phi, step,
-                                      c->stream);
+        const bool first = i == 0, split = iterations > 1;
+        hipStream_t on = first ? c->stream : c->filterStream;
+        // (a later pass reads normals / positions at its taps: inside the rectangle pass 0 filtered, or outside the image)
+        const uint32_t *nrm = first ? (const uint32_t *)c->normal.p : (const uint32_t *)c->normalCopy.p;
+        const uint2 *pos = first ? (const uint2 *)c->pos.p : (const uint2 *)c->posCopy.p;
+        SpanGuard span(c, TK_FILTER, true, on);
+        hipError_t e = rtLaunchAtrous(readF32, readF16, nrm, pos, (uint2 *)c->filt[write].p,
+                                      first && split ? (uint32_t *)c->normalCopy.p : nullptr,
+                                      first && split ? (uint2 *)c->posCopy.p : nullptr, c->width, c->height, r, c_phi, n_phi,
+                                      p_phi, step, on);
         span.end();
         if (e != hipSuccess) return hipFail(c, e, "atrous launch");
+        if (first && split) {
+            HIP_TRY(c, hipEventRecord(c->filterFed, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->filterStream, c->filterFed, 0));
+        }
         readF32 = nullptr;
         readF16 = (const uint2 *)c->filt[write].p;
         c->filteredIndex = write;
         write ^= 1;
+    }
+    if (iterations > 1) {
+        HIP_TRY(c, hipEventRecord(c->filterDone, c->filterStream));
+        c->filterPending = true;
     }
     return RT_OK;
 }
@@ -958,6 +1023,7 @@ int rt_tonemap(rt_ctx *c, int source_image, float exposure, const rt_rect *tile)
     int rc = bind(c);
     if (rc) return rc;
     if (source_image == RT_IMAGE_ASSEMBLED && (rc = rtCommOrderAfterGather(c))) return rc;
+    if (source_image == RT_IMAGE_FILTERED && (rc = rtJoinFilter(c))) return rc;
     SpanGuard span(c, TK_TONEMAP);
     hipError_t e = rtLaunchTonemap(f32, f16, (uint32_t *)c->ldr.p, c->width, r, exposure, c->stream);
     span.end();
@@ -974,6 +1040,7 @@ int rt_readback(rt_ctx *c, int image, void *dst, size_t nbytes) {
     int rc = bind(c);
     if (rc) return rc;
     if (image == RT_IMAGE_ASSEMBLED && (rc = rtCommOrderAfterGather(c))) return rc;
+    if (image == RT_IMAGE_FILTERED && (rc = rtJoinFilter(c))) return rc;
     HIP_TRY(c, hipMemcpyAsync(dst, im.p, need, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -988,6 +1055,7 @@ int rt_write_image(rt_ctx *c, int image, const void *src, size_t nbytes) {
     if (nbytes != need) return fail(c, RT_EINVAL, "rt_write_image: size mismatch, need " + std::to_string(need));
     int rc = bind(c);
     if (rc) return rc;
+    if (image == RT_IMAGE_FILTERED && (rc = rtJoinFilter(c))) return rc;
     HIP_TRY(c, hipMemcpyAsync(im.p, src, need, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -1005,6 +1073,7 @@ static int rectCopy(rt_ctx *c, int image, const rt_rect *tile, void *dev, size_t
     if (rowBytes == 0 || rows == 0) return RT_OK;
     int rc = bind(c);
     if (rc) return rc;
+    if (image == RT_IMAGE_FILTERED && (rc = rtJoinFilter(c))) return rc;
     char *imgAt = (char *)im.p + ((size_t)r.y0 * c->width + r.x0) * im.pixelBytes;
     const size_t pitch = (size_t)c->width * im.pixelBytes;
     if (toCaller) HIP_TRY(c, hipMemcpy2DAsync(dev, rowBytes, imgAt, pitch, rowBytes, rows, hipMemcpyDeviceToDevice, c->stream));
@@ -1085,6 +1154,8 @@ int rt_sync(rt_ctx *c) {
     int rc = bind(c);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->filterStream));
+    c->filterPending = false;
     rtCommQuiesce(c);
     return RT_OK;
 }

@@ -360,6 +360,46 @@ class _CustomWorkload:
         self.num_emitters = self.info.num_emitters
 
 
+def test_filter_passes_overlap_the_next_trace(ctx):
+    """rt_filter runs its later passes on a second stream from a private copy of the G-buffer, so the next frame's
+    trace (queued at once, no sync) rewrites colour / normals / positions while they run: the filtered image must be
+    the one of the frame that was filtered, and the next filter must wait for the previous one."""
+    w, h = 640, 360
+    wl = workloads.Workload("room", w, h)
+    other = workloads.Workload("scene", w, h)   # another camera: every G-buffer texel changes
+    ctx.upload_scene(wl.buffers)
+    ctx.resize(w, h)
+
+    def frame(rays, eye, k):
+        ctx.trace_samples(rays, eye, spp=2, frame0=2 * k, max_bounces=3, num_emitters=wl.num_emitters)
+
+    frame(wl.rays, wl.eye, 0)
+    ctx.filter(5)
+    ctx.sync()
+    want_a = ctx.readback(hiplib.IMAGE_FILTERED).copy()
+    frame(other.rays, other.eye, 1)
+    ctx.filter(5)
+    ctx.sync()
+    want_b = ctx.readback(hiplib.IMAGE_FILTERED).copy()
+    assert not np.array_equal(want_a, want_b)
+    for _ in range(3):  # queued back to back
+        frame(wl.rays, wl.eye, 0)
+        ctx.filter(5)
+        frame(other.rays, other.eye, 1)          # overwrites the G-buffer while passes 1..4 of the first frame run
+        got_a = ctx.readback(hiplib.IMAGE_FILTERED)
+        ctx.filter(5)                            # must wait for the passes above (same ping-pong images)
+        frame(wl.rays, wl.eye, 0)
+        got_b = ctx.readback(hiplib.IMAGE_FILTERED)
+        assert np.array_equal(got_a.view(np.uint16), want_a.view(np.uint16))
+        assert np.array_equal(got_b.view(np.uint16), want_b.view(np.uint16))
+    # a tile: pass 0 copies the G-buffer only where it filtered, which is all the later passes read
+    frame(wl.rays, wl.eye, 0)
+    ctx.filter(5, rect=(100, 50, 400, 300))
+    frame(other.rays, other.eye, 1)
+    got = ctx.readback(hiplib.IMAGE_FILTERED)
+    assert np.array_equal(got[50:300, 100:400].view(np.uint16), want_a[50:300, 100:400].view(np.uint16))
+
+
 def test_weighted_lights_flag(ctx):
     """RT_FLAG_WEIGHTED_LIGHTS: the emitter pick of the block the reference keeps commented out (random.glsl:223-248),
     against the llvmpipe fixture made with that block enabled, against the oracle on scenes where the block's
