@@ -55,10 +55,9 @@ template <int TX, int TY, bool BANDS>
 __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict__ colorF32,
                                                         const uint2 *__restrict__ colorF16,
                                                         const uint32_t *__restrict__ normal,
-                                                        const uint2 *__restrict__ pos, uint2 *__restrict__ out,
-                                                        uint32_t *__restrict__ normalCopy,
-                                                        uint2 *__restrict__ posCopy, int W, int H, rt_rect rect,
-                                                        int tilesX, float c_phi, float n_phi, float p_phi, int step) {
+                                                        const uint2 *__restrict__ pos, uint2 *__restrict__ out, int W,
+                                                        int H, rt_rect rect, int tilesX, float c_phi, float n_phi,
+                                                        float p_phi, int step) {
     static_assert(TX * TY == 256, "one pixel per thread");
     extern __shared__ __align__(16) unsigned char lds[];
     const int cols = TX + 2 * step;
@@ -170,10 +169,6 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
         q = make_float4(sum.x / cum_w, sum.y / cum_w, sum.z / cum_w, sum.w / cum_w);
     }
     out[(size_t)y * W + x] = make_uint2(pack_half2_rtz(q.x, q.y), pack_half2_rtz(q.z, q.w));
-    if (normalCopy) { // pass 0 of rt_filter: the later passes read the G-buffer from this copy (rt_launcher.hip)
-        normalCopy[(size_t)y * W + x] = normal[(size_t)y * W + x];
-        posCopy[(size_t)y * W + x] = pos[(size_t)y * W + x];
-    }
 }
 
 // quad.fs:10-22: mapped = 1 - exp(-hdr * exposure); pow(mapped, 1/2.2); alpha 1; 8-bit unorm store.
@@ -203,8 +198,8 @@ __global__ __launch_bounds__(256) void rt_tonemap_kernel(const float4 *__restric
 int rtAtrousMaxStep() { return FT_MAXSTEP; }
 
 hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const uint32_t *normal, const uint2 *pos,
-                          uint2 *out, uint32_t *normalCopy, uint2 *posCopy, int W, int H, const rt_rect &rect, float c_phi,
-                          float n_phi, float p_phi, int step, hipStream_t stream) {
+                          uint2 *out, int W, int H, const rt_rect &rect, float c_phi, float n_phi, float p_phi,
+                          int step, hipStream_t stream) {
     const int rw = rect.x1 - rect.x0, rh = rect.y1 - rect.y0;
     if (rw <= 0 || rh <= 0) return hipSuccess;
     // tile shape by step width: the fewest staged texels per output pixel (48 bytes of LDS each)
@@ -212,7 +207,7 @@ hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const u
         const int tilesX = (rw + TX - 1) / TX, tilesY = (rh + TY - 1) / TY;
         const size_t ldsBytes = (size_t)(bands ? 3 * TY : TY + 2 * step) * (TX + 2 * step) * 48;
         hipLaunchKernelGGL(kernel, dim3(tilesX * tilesY), dim3(256), ldsBytes, stream, colorF32, colorF16, normal, pos,
-                           out, normalCopy, posCopy, W, H, rect, tilesX, c_phi, n_phi, p_phi, step);
+                           out, W, H, rect, tilesX, c_phi, n_phi, p_phi, step);
     };
     if (step <= 2) launch(rt_atrous_kernel<16, 16, false>, 16, 16, false);
     else if (step <= 4) launch(rt_atrous_kernel<32, 8, false>, 32, 8, false);

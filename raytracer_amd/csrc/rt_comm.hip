@@ -182,7 +182,6 @@ int rt_gather_tiles(rt_ctx *c, int image, const rt_rect *rects, int nrects, int 
     int rc = bind(c);
     if (rc) return rc;
     if ((rc = ensureCommStream(c))) return rc;
-    if (image == RT_IMAGE_FILTERED && (rc = rtJoinFilter(c))) return rc; // the tile is packed on the context's stream
     const size_t pb = im.pixelBytes;
     auto rowBytes = [&](const rt_rect &r) { return (size_t)(r.x1 - r.x0) * pb; };
     auto rows = [&](const rt_rect &r) { return (size_t)(r.y1 - r.y0); };

@@ -45,8 +45,19 @@ struct rt_ctx {
     int filteredIndex = -1; // which of filt[] holds the result of the last rt_filter
 
     // wavefront path tracer state (wavefront.h), grown on demand
-    DevBuf wfState[8], wfRay[6], wfQueue[2], wfCounts, wfRadiance, wfPrimPix;
-    size_t wfCapacity = 0, wfRadianceSlots = 0;
+    // Wavefront pipeline memory, one set per LANE.  Two frames may be in flight: successive rt_trace_batch calls
+    // alternate between two lanes (own stream, own pipeline memory, own staging copy of the G-buffer); what a frame
+    // writes to the caller-visible images (colour, normals, positions) is written by its last kernel only, which waits
+    // for everything queued before the call.  See wavefrontFrame in rt_launcher.hip.
+    struct Lane {
+        hipStream_t stream = nullptr;   // lane 0: the context's own stream; lane 1: a second stream
+        DevBuf wfState[8], wfRay[6], wfQueue[2], wfCounts, wfRadiance, wfPrimPix;
+        DevBuf stageNormal, stagePos;   // the frame's G-buffer until its last kernel commits it
+        size_t wfCapacity = 0, wfRadianceSlots = 0;
+        hipEvent_t tick = nullptr;      // recorded on the lane's stream when the other lane (or a join) needs to wait for it
+    } lane[2];
+    int laneNow = 0;                    // lane of the stream that `stream` currently is (when it is one of ours)
+    int tunePipeline = 1;               // RT_PIPELINE=0: one frame at a time
     int tuneRefillLanes = 0, tuneExtendBlocks = 4;  // development knobs: RT_WF_REFILL (0: by scene size), RT_WF_BLOCKS
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
     int tuneWalkStop = 0, tuneWalkMin = 0;           // RT_WF_WALK_STOP (eighths), RT_WF_WALK_MIN: 0 = by scene size (WfParams::walkStop)
@@ -68,12 +79,6 @@ struct rt_ctx {
     bool countsPending = false, havePrediction = false;
     int predictedCounts[32] = {};
     long long predictionKey = -1;       // tile / batch / bounces the prediction belongs to
-    // rt_filter: pass 0 runs on `stream` and leaves a private copy of the normals / positions it read; the later passes
-    // run on filterStream from that copy, so the next frame's trace (which rewrites the G-buffer) does not wait for them
-    hipStream_t filterStream = nullptr;
-    hipEvent_t filterFed = nullptr, filterDone = nullptr; // pass 0 finished (on stream); last pass finished (on filterStream)
-    bool filterPending = false;                            // filterDone has been recorded and not yet been waited for
-    DevBuf normalCopy, posCopy;
     hipEvent_t chainEvent = nullptr;    // the stop event recorded last, if nothing was enqueued after it: the next
     bool chainValid = false;            // span starts there instead of recording an event of its own (3 us each)
     long long pendingKey = -1;          // ... and the read-back in flight
@@ -199,7 +204,7 @@ inline ImageRef imageOf(rt_ctx *c, int image) {
 }
 
 
-// rt_launcher.hip: orders the context's stream after the filter passes still running on filterStream (no host wait)
-int rtJoinFilter(rt_ctx *c);
+// rt_launcher.hip: orders the context's current stream after the work the lanes' streams still hold (no host wait)
+int rtJoinLanes(rt_ctx *c);
 
 #endif

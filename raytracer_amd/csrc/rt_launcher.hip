@@ -24,8 +24,8 @@ hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace
 struct rt_ctx;
 void rtMarkKernel(void *ctxOpaque, int kind, bool begin);
 hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const uint32_t *normal, const uint2 *pos,
-                          uint2 *out, uint32_t *normalCopy, uint2 *posCopy, int W, int H, const rt_rect &rect, float c_phi,
-                          float n_phi, float p_phi, int step, hipStream_t stream);
+                          uint2 *out, int W, int H, const rt_rect &rect, float c_phi, float n_phi, float p_phi,
+                          int step, hipStream_t stream);
 hipError_t rtLaunchTonemap(const float4 *colorF32, const uint2 *colorF16, uint32_t *out, int W, const rt_rect &rect,
                            float exposure, hipStream_t stream);
 int rtAtrousMaxStep();
@@ -126,14 +126,14 @@ void spanStop(rt_ctx *c, TimedSpan &s, hipStream_t stream = nullptr) {
     }
 }
 
-// Whatever reads or rewrites what the filter's later passes use (the filtered images, the G-buffer copy) is ordered
-// after them: the context's stream waits for the event of the last pass (no host wait).
-int joinFilter(rt_ctx *c) { return rtJoinFilter(c); }
 } // namespace
-int rtJoinFilter(rt_ctx *c) {
-    if (c->filterPending) {
-        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->filterDone, 0));
-        c->filterPending = false;
+// Orders the context's current stream after whatever the lanes' streams still hold (two frames in flight): called by
+// every entry point that reads or writes what a frame reads or writes, except the pipelined trace and the filter.
+int rtJoinLanes(rt_ctx *c) {
+    for (rt_ctx::Lane &L : c->lane) {
+        if (!L.stream || L.stream == c->stream || !L.tick) continue;
+        HIP_TRY(c, hipEventRecord(L.tick, L.stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, L.tick, 0));
     }
     return RT_OK;
 }
@@ -209,14 +209,6 @@ size_t rt_image_pixel_bytes(int image) {
     }
 }
 
-// The later filter passes fill the SIMDs the next frame's sparse trace stages leave idle; the trace is the critical
-// path, so their stream gets the lowest priority the device offers.
-static bool createFilterStream(rt_ctx *c) {
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-    return hipStreamCreateWithPriority(&c->filterStream, hipStreamNonBlocking, least) == hipSuccess;
-}
-
 int rt_create(int device_id, rt_ctx **out) {
     if (!out) return RT_EINVAL;
     *out = nullptr;
@@ -230,6 +222,16 @@ int rt_create(int device_id, rt_ctx **out) {
         return RT_ENODEV;
     }
     c->stream = c->ownStream;
+    c->lane[0].stream = c->ownStream;
+    // (a second lane that cannot be set up only means one frame at a time)
+    if (hipStreamCreateWithFlags(&c->lane[1].stream, hipStreamNonBlocking) != hipSuccess) c->lane[1].stream = nullptr;
+    for (rt_ctx::Lane &L : c->lane)
+        if (hipEventCreateWithFlags(&L.tick, hipEventDisableTiming) != hipSuccess) L.tick = nullptr;
+    if (!c->lane[0].tick || !c->lane[1].tick) {
+        if (c->lane[1].stream) (void)hipStreamDestroy(c->lane[1].stream);
+        c->lane[1].stream = nullptr;
+    }
+    if (const char *e = std::getenv("RT_PIPELINE")) c->tunePipeline = std::atoi(e) != 0;
     // Device address of the static scratch array on THIS device (each GPU holds its own copy): looked up once per
     // device, with that device current, and used from then on wherever host code needs the array's memory.
     if (device_id < RT_MAX_DEVICES && !rtStaticScratchPtr[device_id]) {
@@ -243,10 +245,7 @@ int rt_create(int device_id, rt_ctx **out) {
         rtStaticScratchPtr[device_id] = ptr;
     }
     if (hipHostMalloc((void **)&c->hostCounts, 32 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&c->countsEvent, hipEventDisableTiming) != hipSuccess ||
-        !createFilterStream(c) ||
-        hipEventCreateWithFlags(&c->filterFed, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->filterDone, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->countsEvent, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(c->ownStream);
         delete c;
         return RT_ENOMEM;
@@ -282,13 +281,9 @@ void rt_destroy(rt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    if (c->filterStream) (void)hipStreamSynchronize(c->filterStream);
+    for (rt_ctx::Lane &L : c->lane)
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
     rtCommRelease(c);
-    if (c->filterFed) (void)hipEventDestroy(c->filterFed);
-    if (c->filterDone) (void)hipEventDestroy(c->filterDone);
-    if (c->filterStream) (void)hipStreamDestroy(c->filterStream);
-    releaseBuf(c->normalCopy);
-    releaseBuf(c->posCopy);
     if (c->countsEvent) (void)hipEventDestroy(c->countsEvent);
     if (c->hostCounts) (void)hipHostFree(c->hostCounts);
     for (TimedSpan &s : c->spans) {
@@ -300,9 +295,15 @@ void rt_destroy(rt_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     DevBuf *all[] = {&c->boxes, &c->leaves, &c->tris48, &c->tris128, &c->mtls, &c->emitters, &c->color, &c->normal,
                      &c->pos, &c->filt[0], &c->filt[1], &c->tridx, &c->visits, &c->stats, &c->ldr, &c->counters,
-                     &c->wfQueue[0], &c->wfQueue[1], &c->wfCounts, &c->wfRadiance, &c->wfPrimPix, &c->spec};
-    for (DevBuf &b : c->wfState) releaseBuf(b);
-    for (DevBuf &b : c->wfRay) releaseBuf(b);
+                     &c->spec};
+    for (rt_ctx::Lane &L : c->lane) {
+        for (DevBuf &b : L.wfState) releaseBuf(b);
+        for (DevBuf &b : L.wfRay) releaseBuf(b);
+        DevBuf *mine[] = {&L.wfQueue[0], &L.wfQueue[1], &L.wfCounts, &L.wfRadiance, &L.wfPrimPix, &L.stageNormal, &L.stagePos};
+        for (DevBuf *b : mine) releaseBuf(*b);
+        if (L.tick) (void)hipEventDestroy(L.tick);
+    }
+    if (c->lane[1].stream) (void)hipStreamDestroy(c->lane[1].stream);
     for (DevBuf *b : all) releaseBuf(*b);
     for (DevBuf &b : c->raw) releaseBuf(b);
     releaseBuf(c->cells);
@@ -318,10 +319,11 @@ int rt_set_stream(rt_ctx *c, void *hip_stream) {
     int r = bind(c);
     if (r) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->filterStream));
-    c->filterPending = false;
+    for (rt_ctx::Lane &L : c->lane)
+        if (L.stream) HIP_TRY(c, hipStreamSynchronize(L.stream));
     c->chainValid = false;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
+    c->laneNow = 0;
     return RT_OK;
 }
 
@@ -330,6 +332,8 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
     if (!bytes && nbytes) return fail(c, RT_EINVAL, "rt_upload: null bytes");
     int r = bind(c);
     if (r) return r;
+    for (rt_ctx::Lane &L : c->lane) // a frame in flight may still read the buffers this call replaces
+        if (L.stream && L.stream != c->stream) HIP_TRY(c, hipStreamSynchronize(L.stream));
     switch (slot) {
     case RT_SLOT_NODES: {
         c->walkTune.state = 0;
@@ -461,6 +465,7 @@ int rt_download(rt_ctx *c, int slot, void *dst, size_t nbytes) {
         return fail(c, RT_EINVAL, "rt_download: size mismatch, need " + std::to_string(c->raw[slot].bytes));
     int r = bind(c);
     if (r) return r;
+    if ((r = rtJoinLanes(c))) return r;
     HIP_TRY(c, hipMemcpyAsync(dst, c->raw[slot].p, nbytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -473,6 +478,7 @@ int rt_set_table(rt_ctx *c, int table, const void *bytes, size_t nbytes) {
     if (nbytes != expect[table]) return fail(c, RT_EINVAL, "rt_set_table: unexpected table size");
     int r = bind(c);
     if (r) return r;
+    if ((r = rtJoinLanes(c))) return r;
     return uploadTo(c, c->tables[table], bytes, nbytes);
 }
 
@@ -482,7 +488,7 @@ int rt_clear(rt_ctx *c) {
     int r = bind(c);
     if (r) return r;
     const size_t n = (size_t)c->width * c->height;
-    if ((r = rtJoinFilter(c))) return r;
+    if ((r = rtJoinLanes(c))) return r;
     HIP_TRY(c, hipMemsetAsync(c->color.p, 0, n * 16, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->normal.p, 0, n * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->pos.p, 0, n * 8, c->stream));
@@ -503,12 +509,11 @@ int rt_resize(rt_ctx *c, int width, int height) {
     int r = bind(c);
     if (r) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->filterStream));
-    c->filterPending = false;
+    for (rt_ctx::Lane &L : c->lane)
+        if (L.stream) HIP_TRY(c, hipStreamSynchronize(L.stream));
     rtCommQuiesce(c);
     if (width != c->width || height != c->height) c->assembledPixelBytes = 0; // the assembled frame belongs to the old size
     const size_t n = (size_t)width * height;
-    if ((r = ensure(c, c->normalCopy, n * 4)) || (r = ensure(c, c->posCopy, n * 8))) return r;
     if ((r = ensure(c, c->color, n * 16)) || (r = ensure(c, c->normal, n * 4)) || (r = ensure(c, c->pos, n * 8)) ||
         (r = ensure(c, c->filt[0], n * 8)) || (r = ensure(c, c->filt[1], n * 8)) || (r = ensure(c, c->tridx, n * 4)) ||
         (r = ensure(c, c->visits, n * 4)) || (r = ensure(c, c->stats, n * 16)) || (r = ensure(c, c->ldr, n * 4)))
@@ -549,47 +554,49 @@ void fillScene(const rt_ctx *c, RtScene &sc, RtImages &img) {
 }
 
 // Device memory of the wavefront pipeline for `capacity` path slots and `radianceSlots` (sample, pixel) pairs.
-int ensureWavefront(rt_ctx *c, size_t capacity, size_t radianceSlots, WfBuffers &wf) {
+int ensureWavefront(rt_ctx *c, rt_ctx::Lane &L, size_t capacity, size_t radianceSlots, WfBuffers &wf) {
     int r;
-    if (capacity > c->wfCapacity) {
+    if (capacity > L.wfCapacity) {
         // grow with some slack so that tiles of slightly different sizes do not re-allocate
         const size_t cap = capacity + capacity / 16;
         for (int k = 0; k < 6; ++k)
-            if ((r = ensure(c, c->wfState[k], cap * 16))) return r;
-        if ((r = ensure(c, c->wfState[6], cap * 8))) return r;  // pixSample
-        if ((r = ensure(c, c->wfState[7], cap * 16))) return r; // pathStats
+            if ((r = ensure(c, L.wfState[k], cap * 16))) return r;
+        if ((r = ensure(c, L.wfState[6], cap * 8))) return r;  // pixSample
+        if ((r = ensure(c, L.wfState[7], cap * 16))) return r; // pathStats
         for (int k = 0; k < 5; ++k)
-            if ((r = ensure(c, c->wfRay[k], 3 * cap * 16))) return r;
-        if ((r = ensure(c, c->wfRay[5], 3 * cap * 8))) return r;
-        if ((r = ensure(c, c->wfQueue[0], cap * 4)) || (r = ensure(c, c->wfQueue[1], cap * 4))) return r;
-        if ((r = ensure(c, c->wfPrimPix, cap * 4))) return r;
-        c->wfCapacity = cap;
+            if ((r = ensure(c, L.wfRay[k], 3 * cap * 16))) return r;
+        if ((r = ensure(c, L.wfRay[5], 3 * cap * 8))) return r;
+        if ((r = ensure(c, L.wfQueue[0], cap * 4)) || (r = ensure(c, L.wfQueue[1], cap * 4))) return r;
+        if ((r = ensure(c, L.wfPrimPix, cap * 4))) return r;
+        L.wfCapacity = cap;
     }
-    if ((r = ensure(c, c->wfCounts, 64 * sizeof(int)))) return r;
-    if (radianceSlots > c->wfRadianceSlots) {
-        if ((r = ensure(c, c->wfRadiance, radianceSlots * 16))) return r;
-        c->wfRadianceSlots = radianceSlots;
+    if ((r = ensure(c, L.wfCounts, 64 * sizeof(int)))) return r;
+    if (radianceSlots > L.wfRadianceSlots) {
+        if ((r = ensure(c, L.wfRadiance, radianceSlots * 16))) return r;
+        L.wfRadianceSlots = radianceSlots;
     }
-    wf.L_seed = (float4 *)c->wfState[0].p;
-    wf.beta = (float4 *)c->wfState[1].p;
-    wf.betaOld = (float4 *)c->wfState[2].p;
-    wf.f1w1 = (float4 *)c->wfState[3].p;
-    wf.f2w2 = (float4 *)c->wfState[4].p;
-    wf.pdfs = (float4 *)c->wfState[5].p;
-    wf.pixSample = (uint2 *)c->wfState[6].p;
-    wf.pathStats = (int4 *)c->wfState[7].p;
-    wf.rayO[0] = (float4 *)c->wfRay[0].p;
-    wf.rayO[1] = (float4 *)c->wfRay[1].p;
-    wf.rayD[0] = (float4 *)c->wfRay[2].p;
-    wf.rayD[1] = (float4 *)c->wfRay[3].p;
-    wf.rayHit = (int4 *)c->wfRay[4].p;
-    wf.rayWork = (int2 *)c->wfRay[5].p;
-    wf.queue[0] = (int *)c->wfQueue[0].p;
-    wf.queue[1] = (int *)c->wfQueue[1].p;
-    wf.counts = (int *)c->wfCounts.p;
-    wf.radiance = (float4 *)c->wfRadiance.p;
-    wf.primPix = (unsigned *)c->wfPrimPix.p;
-    wf.capacity = (int)c->wfCapacity;
+    wf.L_seed = (float4 *)L.wfState[0].p;
+    wf.beta = (float4 *)L.wfState[1].p;
+    wf.betaOld = (float4 *)L.wfState[2].p;
+    wf.f1w1 = (float4 *)L.wfState[3].p;
+    wf.f2w2 = (float4 *)L.wfState[4].p;
+    wf.pdfs = (float4 *)L.wfState[5].p;
+    wf.pixSample = (uint2 *)L.wfState[6].p;
+    wf.pathStats = (int4 *)L.wfState[7].p;
+    wf.rayO[0] = (float4 *)L.wfRay[0].p;
+    wf.rayO[1] = (float4 *)L.wfRay[1].p;
+    wf.rayD[0] = (float4 *)L.wfRay[2].p;
+    wf.rayD[1] = (float4 *)L.wfRay[3].p;
+    wf.rayHit = (int4 *)L.wfRay[4].p;
+    wf.rayWork = (int2 *)L.wfRay[5].p;
+    wf.queue[0] = (int *)L.wfQueue[0].p;
+    wf.queue[1] = (int *)L.wfQueue[1].p;
+    wf.counts = (int *)L.wfCounts.p;
+    wf.radiance = (float4 *)L.wfRadiance.p;
+    wf.primPix = (unsigned *)L.wfPrimPix.p;
+    wf.stageNormal = nullptr;
+    wf.stagePos = nullptr;
+    wf.capacity = (int)L.wfCapacity;
     return RT_OK;
 }
 
@@ -610,7 +617,7 @@ namespace {
 // noAlloc: called by rt_trace_batch_static — nothing here may allocate (no event creation either), so the launch is
 // neither profiled nor used to time the WalkTune candidates; the schedule that is picked cannot change the picture.
 int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rect &r, const RtScene &sc,
-                   const RtImages &img, WfBuffers &wf, bool noAlloc) {
+                   const RtImages &img, WfBuffers &wf, bool noAlloc, hipEvent_t beforeCommit = nullptr) {
     const rt_trace_params *p = &params[0];
     const size_t hot = c->boxes.bytes + c->leaves.bytes + c->tris48.bytes;
     const int xcdRemap = hot > (size_t)3 * 1024 * 1024;
@@ -704,7 +711,7 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     const bool profiled = c->profile && !noAlloc;
     rt_ctx *spanCtx = c;
     SpanGuard span(spanCtx, TK_TRACE, profiled);
-    hipError_t e = rtLaunchWavefront(sc, img, wp, wf, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream,
+    hipError_t e = rtLaunchWavefront(sc, img, wp, wf, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream, beforeCommit,
                                      profiled ? c : nullptr, predicted);
     span.end();
     if (e == hipSuccess && !c->countsPending) { // (one read-back in flight at a time: hostCounts is a single buffer)
@@ -760,6 +767,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         const bool perPixel = (p->flags & RT_FLAG_PER_PIXEL_KERNEL) || p->maxBounces > 30 ||
                               tilePixels * (size_t)n > ((size_t)1 << 30);
         if (perPixel) {
+            if ((rc = rtJoinLanes(c))) return rc;
             for (int k = 0; k < n; ++k) {
                 SpanGuard span(c, TK_TRACE), span2(c, RT_TIME_PER_PIXEL);
                 rt_trace_params pk = params[k];
@@ -771,11 +779,39 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             }
             return RT_OK;
         }
+        // Two frames in flight.  This frame runs on the lane the previous call did not use (own stream, own pipeline
+        // memory); the normals / positions it produces are staged and its last kernel, which also blends the colour,
+        // copies them to the images — after waiting for everything queued before this call (the previous frame's
+        // commit, the filter pass that reads its G-buffer, a gather's pack).  Not while the launcher still times its
+        // schedule candidates, not with the per-pixel side images (written early), not on a caller's stream.
+        const bool ours = c->stream == c->lane[0].stream || c->stream == c->lane[1].stream;
+        const size_t laneBytes = tilePixels * (size_t)n * rtWavefrontBytesPerPath();
+        const bool pipelined = c->tunePipeline && ours && c->lastWalkSettled && c->lane[1].stream &&
+                               !(p->flags & (RT_FLAG_AUX | RT_FLAG_PIXEL_STATS)) && laneBytes <= ((size_t)24 << 30);
+        hipEvent_t before = nullptr;
+        if (pipelined) {
+            rt_ctx::Lane &prev = c->lane[c->laneNow];
+            HIP_TRY(c, hipEventRecord(prev.tick, c->stream));
+            before = prev.tick;
+            c->laneNow ^= 1;
+            c->stream = c->lane[c->laneNow].stream;
+            c->chainValid = false;
+        } else if ((rc = rtJoinLanes(c))) {
+            return rc;
+        }
+        rt_ctx::Lane &L = c->lane[ours ? c->laneNow : 0];
         WfBuffers wf;
-        if ((rc = ensureWavefront(c, tilePixels * (size_t)n, tilePixels * (size_t)n, wf))) return rc;
-        return wavefrontFrame(c, params, n, r, sc, img, wf, false);
+        if ((rc = ensureWavefront(c, L, tilePixels * (size_t)n, tilePixels * (size_t)n, wf))) return rc;
+        if (pipelined) {
+            const size_t px = (size_t)c->width * c->height;
+            if ((rc = ensure(c, L.stageNormal, px * 4)) || (rc = ensure(c, L.stagePos, px * 8))) return rc;
+            wf.stageNormal = (uint32_t *)L.stageNormal.p;
+            wf.stagePos = (uint2 *)L.stagePos.p;
+        }
+        return wavefrontFrame(c, params, n, r, sc, img, wf, false, before);
     }
     case RT_KERNEL_TRACE3_RL: {
+        if ((rc = rtJoinLanes(c))) return rc;
         // traceRL (reference trace3.cs:695-791): the scene of trace3 plus the Q-table state of slots 7..10.
         if (!c->boxes.p || !c->tris48.p || !c->mtls.p)
             return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
@@ -819,6 +855,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         return RT_OK;
     }
     case RT_KERNEL_TRACE: case RT_KERNEL_TRACE1: case RT_KERNEL_TRACE2: {
+        if ((rc = rtJoinLanes(c))) return rc;
         // The analytic-scene kernels: no scene buffers; trace1 reads the blue-noise tables when useBlueNoise is
         // set, trace2 the two LTC look-up tables (reference src/Tracer.cpp:23-90).
         if (p->kernel == RT_KERNEL_TRACE1 && p->useBlueNoise &&
@@ -904,6 +941,7 @@ int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const
     if (tilePixels == 0) return RT_OK;
     int rc = bind(c);
     if (rc) return rc;
+    if ((rc = rtJoinLanes(c))) return rc; // (two event calls on events made at rt_create: nothing is allocated)
     unsigned char *base = c->device < RT_MAX_DEVICES ? (unsigned char *)rtStaticScratchPtr[c->device] : nullptr;
     if (!base) return fail(c, RT_ESTATE, "rt_trace_batch_static: the static scratch array was not resolved on this device");
     RtScene sc;
@@ -927,6 +965,8 @@ int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const
     wf.rayD[1] = (float4 *)take(kStaticRay16);
     wf.rayHit = (int4 *)take(kStaticRay16);
     wf.rayWork = (int2 *)take(kStaticRay8);
+    wf.stageNormal = nullptr;
+    wf.stagePos = nullptr;
     wf.queue[0] = (int *)take(kStaticQueue);
     wf.queue[1] = (int *)take(kStaticQueue);
     wf.primPix = (unsigned *)take(kStaticQueue);
@@ -954,11 +994,9 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
         return fail(c, RT_EINVAL, "rt_filter: step width beyond the LDS tile limit (iterations <= 6)");
     int rc = bind(c);
     if (rc) return rc;
-    // Filter::filter, reference src/filter.cpp:68-104.  Pass 0 runs on the context's stream and leaves a copy of the
-    // normals / positions of the pixels it filtered; the later passes run on filterStream and read that copy, so the
-    // next frame's trace may rewrite the G-buffer while they run.  Whoever touches the filtered images or starts
-    // another filter is ordered after them by joinFilter (an event wait on the stream, never on the host).
-    if ((rc = joinFilter(c))) return rc;
+    // Filter::filter, reference src/filter.cpp:68-104.  All passes run on the context's current stream, i.e. on the lane
+    // of the frame just traced: with two frames in flight the next frame's trace runs beside them on the other lane
+    // and only its last kernel (which rewrites colour, normals and positions) waits for them.
     const float4 *readF32 = (const float4 *)c->color.p;
     const uint2 *readF16 = nullptr;
     int write = 0;
@@ -975,30 +1013,16 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
         r.y0 = target.y0 - grow < 0 ? 0 : target.y0 - grow;
         r.x1 = target.x1 + grow > c->width ? c->width : target.x1 + grow;
         r.y1 = target.y1 + grow > c->height ? c->height : target.y1 + grow;
-        const bool first = i == 0, split = iterations > 1;
-        hipStream_t on = first ? c->stream : c->filterStream;
-        // (a later pass reads normals / positions at its taps: inside the rectangle pass 0 filtered, or outside the image)
-        const uint32_t *nrm = first ? (const uint32_t *)c->normal.p : (const uint32_t *)c->normalCopy.p;
-        const uint2 *pos = first ? (const uint2 *)c->pos.p : (const uint2 *)c->posCopy.p;
-        SpanGuard span(c, TK_FILTER, true, on);
-        hipError_t e = rtLaunchAtrous(readF32, readF16, nrm, pos, (uint2 *)c->filt[write].p,
-                                      first && split ? (uint32_t *)c->normalCopy.p : nullptr,
-                                      first && split ? (uint2 *)c->posCopy.p : nullptr, c->width, c->height, r, c_phi, n_phi,
-                                      p_phi, step, on);
+        SpanGuard span(c, TK_FILTER);
+        hipError_t e = rtLaunchAtrous(readF32, readF16, (const uint32_t *)c->normal.p, (const uint2 *)c->pos.p,
+                                      (uint2 *)c->filt[write].p, c->width, c->height, r, c_phi, n_phi, p_phi, step,
+                                      c->stream);
         span.end();
         if (e != hipSuccess) return hipFail(c, e, "atrous launch");
-        if (first && split) {
-            HIP_TRY(c, hipEventRecord(c->filterFed, c->stream));
-            HIP_TRY(c, hipStreamWaitEvent(c->filterStream, c->filterFed, 0));
-        }
         readF32 = nullptr;
         readF16 = (const uint2 *)c->filt[write].p;
         c->filteredIndex = write;
         write ^= 1;
-    }
-    if (iterations > 1) {
-        HIP_TRY(c, hipEventRecord(c->filterDone, c->filterStream));
-        c->filterPending = true;
     }
     return RT_OK;
 }
@@ -1023,7 +1047,7 @@ int rt_tonemap(rt_ctx *c, int source_image, float exposure, const rt_rect *tile)
     int rc = bind(c);
     if (rc) return rc;
     if (source_image == RT_IMAGE_ASSEMBLED && (rc = rtCommOrderAfterGather(c))) return rc;
-    if (source_image == RT_IMAGE_FILTERED && (rc = rtJoinFilter(c))) return rc;
+    if ((rc = rtJoinLanes(c))) return rc;
     SpanGuard span(c, TK_TONEMAP);
     hipError_t e = rtLaunchTonemap(f32, f16, (uint32_t *)c->ldr.p, c->width, r, exposure, c->stream);
     span.end();
@@ -1040,7 +1064,7 @@ int rt_readback(rt_ctx *c, int image, void *dst, size_t nbytes) {
     int rc = bind(c);
     if (rc) return rc;
     if (image == RT_IMAGE_ASSEMBLED && (rc = rtCommOrderAfterGather(c))) return rc;
-    if (image == RT_IMAGE_FILTERED && (rc = rtJoinFilter(c))) return rc;
+    if ((rc = rtJoinLanes(c))) return rc;
     HIP_TRY(c, hipMemcpyAsync(dst, im.p, need, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -1055,7 +1079,7 @@ int rt_write_image(rt_ctx *c, int image, const void *src, size_t nbytes) {
     if (nbytes != need) return fail(c, RT_EINVAL, "rt_write_image: size mismatch, need " + std::to_string(need));
     int rc = bind(c);
     if (rc) return rc;
-    if (image == RT_IMAGE_FILTERED && (rc = rtJoinFilter(c))) return rc;
+    if ((rc = rtJoinLanes(c))) return rc;
     HIP_TRY(c, hipMemcpyAsync(im.p, src, need, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -1073,7 +1097,7 @@ static int rectCopy(rt_ctx *c, int image, const rt_rect *tile, void *dev, size_t
     if (rowBytes == 0 || rows == 0) return RT_OK;
     int rc = bind(c);
     if (rc) return rc;
-    if (image == RT_IMAGE_FILTERED && (rc = rtJoinFilter(c))) return rc;
+    if ((rc = rtJoinLanes(c))) return rc;
     char *imgAt = (char *)im.p + ((size_t)r.y0 * c->width + r.x0) * im.pixelBytes;
     const size_t pitch = (size_t)c->width * im.pixelBytes;
     if (toCaller) HIP_TRY(c, hipMemcpy2DAsync(dev, rowBytes, imgAt, pitch, rowBytes, rows, hipMemcpyDeviceToDevice, c->stream));
@@ -1098,6 +1122,7 @@ int rt_counters_read(rt_ctx *c, rt_counters *out) {
     if (!c || !out) return RT_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
+    if ((rc = rtJoinLanes(c))) return rc;
     std::vector<RtCountersDev> h(RT_COUNTER_SHARDS);
     HIP_TRY(c, hipMemcpyAsync(h.data(), c->counters.p, sizeof(RtCountersDev) * RT_COUNTER_SHARDS, hipMemcpyDeviceToHost,
                               c->stream));
@@ -1122,6 +1147,7 @@ int rt_counters_reset(rt_ctx *c) {
     if (!c) return RT_EINVAL;
     int rc = bind(c);
     if (rc) return rc;
+    if ((rc = rtJoinLanes(c))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(RtCountersDev) * RT_COUNTER_SHARDS, c->stream));
     return RT_OK;
 }
@@ -1154,8 +1180,8 @@ int rt_sync(rt_ctx *c) {
     int rc = bind(c);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->filterStream));
-    c->filterPending = false;
+    for (rt_ctx::Lane &L : c->lane)
+        if (L.stream) HIP_TRY(c, hipStreamSynchronize(L.stream));
     rtCommQuiesce(c);
     return RT_OK;
 }

@@ -55,13 +55,21 @@ struct WfBuffers {
     unsigned *primPix;  // stage-0 queue: pixel index of entry j (one entry per PIXEL: the primary ray is the same for
                         // every sample of a batch, trace3.cs:805-806, so it is traced once and logic(0) fans out)
     float4 *radiance;   // [sample][pixel in tile] finished L
+    // Two frames in flight (rt_launcher.hip): the frame's normals / positions go to these full-size staging images
+    // and the blend kernel, the frame's last, copies the tile's texels to the caller-visible ones.  Null: written
+    // straight to the images.
+    uint32_t *stageNormal;
+    uint2 *stagePos;
     int capacity;
     int tilePixels;
 };
 
 // predictedCounts: queue sizes per stage of a similar earlier frame (32 ints), or null when there is none
+// beforeCommit: an event the stream waits for before the blend kernel (the only kernel that writes caller-visible
+// images when the G-buffer is staged), or null
 hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfParams &p, const WfBuffers &wf,
                              const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream,
+                             hipEvent_t beforeCommit,
                              void *profileCtx, const int *predictedCounts);
 void rtMarkKernel(void *ctxOpaque, int kind, bool begin);
 // bytes of device memory per unit of capacity (one path slot) and per (sample, tile pixel)

@@ -1024,17 +1024,26 @@ __global__ __launch_bounds__(256) void rt_wf_blend_kernel(RtImages img, WfParams
             cur = make_float4(fin.x, fin.y, fin.z, 1.0f);
         }
         img.color[pix] = cur;
+        if (wf.stageNormal) { // the frame's G-buffer becomes visible with its colour
+            img.normal[pix] = wf.stageNormal[pix];
+            img.pos[pix] = wf.stagePos[pix];
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------ host
 size_t rtWavefrontBytesPerPath() { return 6 * 16 + 8 + 16 + 3 * (4 * 16 + 16 + 8) + 2 * 4; }
 
-hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfParams &p, const WfBuffers &wf,
+hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const WfParams &p, const WfBuffers &wf,
                              const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream,
-                             void *prof, const int *predictedCounts) {
+                             hipEvent_t beforeCommit, void *prof, const int *predictedCounts) {
     const int tw = tile.x1 - tile.x0, th = tile.y1 - tile.y0;
     if (tw <= 0 || th <= 0 || p.batch <= 0) return hipSuccess;
+    RtImages img = imgOut; // what the kernels before the blend write: the staged G-buffer when there is one
+    if (wf.stageNormal) {
+        img.normal = wf.stageNormal;
+        img.pos = wf.stagePos;
+    }
     hipError_t e = hipMemsetAsync(wf.counts, 0, 64 * sizeof(int), stream);
     if (e != hipSuccess) return e;
     const int tilesX = (tw + 15) / 16, tilesY = (th + 15) / 16;
@@ -1090,8 +1099,12 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfPar
     }
     int blendBlocks = (tw * th + 255) / 256;
     if (blendBlocks > 4096) blendBlocks = 4096;
+    if (beforeCommit) {
+        hipError_t w = hipStreamWaitEvent(stream, beforeCommit, 0);
+        if (w != hipSuccess) return w;
+    }
     if (prof) rtMarkKernel(prof, RT_TIME_WF_BLEND, true);
-    hipLaunchKernelGGL(rt_wf_blend_kernel, dim3(blendBlocks), dim3(256), 0, stream, img, p, wf, tile);
+    hipLaunchKernelGGL(rt_wf_blend_kernel, dim3(blendBlocks), dim3(256), 0, stream, imgOut, p, wf, tile);
     if (prof) rtMarkKernel(prof, RT_TIME_WF_BLEND, false);
     return hipGetLastError();
 }

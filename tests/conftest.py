@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# PyTorch-ROCm bundles its own HIP runtime and RCCL (same sonames as /opt/rocm's).  Some tests use torch next to the
+# launcher; the process must then load torch's copies FIRST ("PyTorch in the same process"): loaded
+# after librt_hip.so / librccl.so.1 of /opt/rocm, the two sets of libraries end in a double free at interpreter exit.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -360,10 +360,11 @@ class _CustomWorkload:
         self.num_emitters = self.info.num_emitters
 
 
-def test_filter_passes_overlap_the_next_trace(ctx):
-    """rt_filter runs its later passes on a second stream from a private copy of the G-buffer, so the next frame's
-    trace (queued at once, no sync) rewrites colour / normals / positions while they run: the filtered image must be
-    the one of the frame that was filtered, and the next filter must wait for the previous one."""
+def test_two_frames_in_flight_keep_their_images_apart(ctx):
+    """Successive rt_trace_batch calls alternate between two lanes (streams): the next frame is traced while the
+    previous one is still being filtered, and only its last kernel — which writes colour, normals and positions —
+    waits for what was queued before it.  Queued back to back without a sync, every filtered image must be the one
+    of the frame that was filtered."""
     w, h = 640, 360
     wl = workloads.Workload("room", w, h)
     other = workloads.Workload("scene", w, h)   # another camera: every G-buffer texel changes
@@ -385,14 +386,14 @@ def test_filter_passes_overlap_the_next_trace(ctx):
     for _ in range(3):  # queued back to back
         frame(wl.rays, wl.eye, 0)
         ctx.filter(5)
-        frame(other.rays, other.eye, 1)          # overwrites the G-buffer while passes 1..4 of the first frame run
+        frame(other.rays, other.eye, 1)          # traced on the other lane while the first frame is being filtered
         got_a = ctx.readback(hiplib.IMAGE_FILTERED)
-        ctx.filter(5)                            # must wait for the passes above (same ping-pong images)
+        ctx.filter(5)                            # same ping-pong images as the filter above: ordered after it
         frame(wl.rays, wl.eye, 0)
         got_b = ctx.readback(hiplib.IMAGE_FILTERED)
         assert np.array_equal(got_a.view(np.uint16), want_a.view(np.uint16))
         assert np.array_equal(got_b.view(np.uint16), want_b.view(np.uint16))
-    # a tile: pass 0 copies the G-buffer only where it filtered, which is all the later passes read
+    # a tile
     frame(wl.rays, wl.eye, 0)
     ctx.filter(5, rect=(100, 50, 400, 300))
     frame(other.rays, other.eye, 1)
