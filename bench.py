@@ -75,6 +75,40 @@ def cpu_baseline(wl, spp, max_bounces, filter_iters, max_follows=1000, budget_s=
                       f"traced {repeats}x in {t_trace:.2f} s each, {filter_iters} filter passes on the full frame in {t_filter:.2f} s"}
 
 
+def alone_roofline(K, ctx, step, steps, wl, W, H, spp, filter_iters, scene_key, root_misses):
+    """The timed region runs with two frames in flight, so its kernel spans are the durations of launches that
+    share the GPU with the other frame's.  This measures the same kernel once more with one frame at a time
+    (outside the timed region): what a launch that has the GPU to itself achieves."""
+    ctx.sync()
+    ctx.set_frames_in_flight(1)
+    try:
+        step()
+        ctx.sync()
+        ctx.reset_counters()
+        ctx.profile(True)
+        ctx.timings(reset=True)
+        for _ in range(steps):
+            step()
+        ctx.sync()
+        cnt, tm = ctx.counters(), ctx.timings()
+        ctx.profile(False)
+        r = roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, root_misses)
+    finally:
+        ctx.set_frames_in_flight(2)
+    if not r:
+        return None
+    return {k: r[k] for k in ("kernel", "achieved", "unit", "frac", "avg_launch_ms", "launches")}
+
+
+def with_alone(rl, alone):
+    if rl is not None:
+        rl["frames_in_flight"] = 2
+        rl["overlap_note"] = ("two frames in flight: a launch shares the GPU with the other frame's kernels, so its span is "
+                              "longer than its cost; one_frame_at_a_time = the same kernel with the GPU to itself")
+        rl["one_frame_at_a_time"] = alone
+    return rl
+
+
 class _GlooGather:
     """torch.distributed.gather over a gloo group (host memory): the exchange bench.py falls back to when the
     launcher's RCCL communicator cannot be set up."""
@@ -214,6 +248,8 @@ def run_case(K, parallel, ctx, device, wl, scene_key, W, H, spp, bounces, filter
     cnt, tm = ctx.counters(), ctx.timings()
     ctx.profile(False)
     rays_per_frame = float(cnt.rays) / steps
+    rl = with_alone(roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, stop_at_root),
+                    alone_roofline(K, ctx, step, steps, wl, W, H, spp, filter_iters, scene_key, stop_at_root))
     out = {"ms_per_frame": round(elapsed * 1e3 / steps, 4), "steps": steps, "warmup": warmup,
            "value": round(float(cnt.rays) / elapsed / 1e6, 3), "unit": "Mrays/s",
            "rays_per_frame": rays_per_frame, "node_visits_per_frame": cnt.node_visits / steps,
@@ -223,7 +259,7 @@ def run_case(K, parallel, ctx, device, wl, scene_key, W, H, spp, bounces, filter
            "rays_per_frame_if_primary_per_sample": rays_per_frame + float((spp - 1) * W * H),
            "walk_stop": ctx.walk_stop(), "schedule_settle_frames": settle,
            "kernel_ms_per_frame": {K.TIME_NAMES[i]: round(tm.ms[i] / steps, 4) for i in range(len(K.TIME_NAMES)) if tm.launches[i]},
-           "roofline": roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, stop_at_root)}
+           "roofline": rl}
     if cpu_budget_s > 0:
         try:
             out["cpu_baseline"] = cpu_baseline(wl, spp, bounces, filter_iters, max_follows, cpu_budget_s)
@@ -369,7 +405,7 @@ def main():
             step()
         fence()
         elapsed = time.perf_counter() - t0
-        return elapsed, ctx.counters(), ctx.timings(), frame, backend, settle
+        return elapsed, ctx.counters(), ctx.timings(), frame, backend, settle, step
 
     # ------------------------------------------------------------------ the headline (driver-timed) measurement
     tileW, tileH = W, H
@@ -420,7 +456,9 @@ def main():
         ctx.resize(W, H)
         hit, stop_at_root = frame_statistics(K, ctx, parallel.HipBackend(ctx, wl, a.spp, a.bounces, a.filter, device,
                                                                        max_follows=max_follows), wl, W, H, a.spp)
-    elapsed, cnt, tm, frame, backend, settle = tiled_run(wl, W, H, a.spp, a.bounces, a.filter, a.steps, a.warmup, max_follows)
+    elapsed, cnt, tm, frame, backend, settle, step = tiled_run(wl, W, H, a.spp, a.bounces, a.filter, a.steps, a.warmup, max_follows)
+    ctx.profile(False)
+    alone = alone_roofline(K, ctx, step, a.steps, wl, W, H, a.spp, a.filter, scene_key, stop_at_root or 0)
 
     frame_sha = None
     if os.environ.get("RT_BENCH_CHECKSUM") and rank == 0:  # rehearsal aid: every N must assemble the same picture
@@ -471,7 +509,7 @@ def main():
         try:
             W4, H4, spp4 = 3840, 2160, 16
             wl4 = workloads.Workload("scene", W4, H4)
-            e4, c4, t4, f4, b4, _ = tiled_run(wl4, W4, H4, spp4, 5, 5, max(2, a.steps // 4), 1, 1000)
+            e4, c4, t4, f4, b4, _, _ = tiled_run(wl4, W4, H4, spp4, 5, 5, max(2, a.steps // 4), 1, 1000)
             ctx.profile(False)
             ctx.reset_counters()
             b4.trace(f4.tile, 0)
@@ -499,7 +537,7 @@ def main():
     frame_rays = sums[6 + len(K.TIME_NAMES)]
     ms_per_step = elapsed * 1e3 / a.steps
     mrays = frame_rays * a.steps / elapsed / 1e6
-    rl = roofline(K, tm, cnt, wl, W, H, a.spp, a.filter, a.steps, scene_key, stop_at_root or 0)
+    rl = with_alone(roofline(K, tm, cnt, wl, W, H, a.spp, a.filter, a.steps, scene_key, stop_at_root or 0), alone)
     frame_name = f"{scene_key}{'.obj' if not lattice else ''} {W}x{H} {a.spp}spp"
     headline = (a.scene, W, H, a.spp, a.bounces, a.filter) == ("scene", 1920, 1080, 4, 5, 5)
     out = {

@@ -209,6 +209,16 @@ size_t rt_image_pixel_bytes(int image) {
     }
 }
 
+int rt_set_frames_in_flight(rt_ctx *c, int n) {
+    if (!c) return RT_EINVAL;
+    if (n != 1 && n != 2) return fail(c, RT_EINVAL, "rt_set_frames_in_flight: 1 or 2");
+    int rc = bind(c);
+    if (rc) return rc;
+    if ((rc = rtJoinLanes(c))) return rc;
+    c->tunePipeline = n == 2;
+    return RT_OK;
+}
+
 int rt_create(int device_id, rt_ctx **out) {
     if (!out) return RT_EINVAL;
     *out = nullptr;

@@ -71,6 +71,7 @@ const RtApi &rtApi() {
     bindSym(lib, "rt_comm_destroy", g_api.comm_destroy);
     bindSym(lib, "rt_gather_tiles", g_api.gather_tiles);
     bindSym(lib, "rt_walk_stop", g_api.walk_stop);
+    bindSym(lib, "rt_set_frames_in_flight", g_api.set_frames_in_flight);
     g_loaded = true;
     return g_api;
 }

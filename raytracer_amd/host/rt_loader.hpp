@@ -33,6 +33,7 @@ struct RtApi {
     int (*comm_destroy)(rt_ctx *);
     int (*gather_tiles)(rt_ctx *, int, const rt_rect *, int, int);
     int (*walk_stop)(const rt_ctx *);
+    int (*set_frames_in_flight)(rt_ctx *, int);
 };
 
 // Loads librt_hip.so (next to librt_host.so, or $RT_HIP_LIB) once; throws std::runtime_error.
