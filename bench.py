@@ -80,6 +80,7 @@ def alone_roofline(K, ctx, step, steps, wl, W, H, spp, filter_iters, scene_key, 
     share the GPU with the other frame's.  This measures the same kernel once more with one frame at a time
     (outside the timed region): what a launch that has the GPU to itself achieves."""
     ctx.sync()
+    before = ctx.frames_in_flight()
     ctx.set_frames_in_flight(1)
     try:
         step()
@@ -94,17 +95,17 @@ def alone_roofline(K, ctx, step, steps, wl, W, H, spp, filter_iters, scene_key, 
         ctx.profile(False)
         r = roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, root_misses)
     finally:
-        ctx.set_frames_in_flight(2)
+        ctx.set_frames_in_flight(before)
     if not r:
         return None
-    return {k: r[k] for k in ("kernel", "achieved", "unit", "frac", "avg_launch_ms", "launches")}
+    return {"frames_in_flight_of_timed_region": before, **{k: r[k] for k in ("kernel", "achieved", "unit", "frac", "avg_launch_ms", "launches")}}
 
 
 def with_alone(rl, alone):
     if rl is not None:
-        rl["frames_in_flight"] = 2
-        rl["overlap_note"] = ("two frames in flight: a launch shares the GPU with the other frame's kernels, so its span is "
-                              "longer than its cost; one_frame_at_a_time = the same kernel with the GPU to itself")
+        rl["frames_in_flight"] = alone.pop("frames_in_flight_of_timed_region") if alone else None
+        rl["overlap_note"] = ("several frames in flight: a launch shares the GPU with the other frames' kernels, so its span "
+                              "is longer than its cost; one_frame_at_a_time = the same kernel with the GPU to itself")
         rl["one_frame_at_a_time"] = alone
     return rl
 

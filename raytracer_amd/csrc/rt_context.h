@@ -18,6 +18,9 @@ struct DevBuf {
 
 enum TimeKind { TK_TRACE = RT_TIME_TRACE, TK_FILTER = RT_TIME_FILTER, TK_TONEMAP = RT_TIME_TONEMAP };
 
+#define RT_MAX_LANES 4
+#define RT_DEFAULT_LANES 3 // (+ the gather's stream = the 4 hardware queues a process gets by default)
+
 struct TimedSpan {
     hipEvent_t start, stop;
     int kind;
@@ -55,9 +58,10 @@ struct rt_ctx {
         DevBuf stageNormal, stagePos;   // the frame's G-buffer until its last kernel commits it
         size_t wfCapacity = 0, wfRadianceSlots = 0;
         hipEvent_t tick = nullptr;      // recorded on the lane's stream when the other lane (or a join) needs to wait for it
-    } lane[2];
+    } lane[RT_MAX_LANES];
     int laneNow = 0;                    // lane of the stream that `stream` currently is (when it is one of ours)
-    int tunePipeline = 1;               // RT_PIPELINE=0: one frame at a time
+    int lanesAvailable = 1;             // lanes whose stream and event could be created
+    int framesInFlight = RT_DEFAULT_LANES; // lanes in use, 1 .. RT_MAX_LANES (rt_set_frames_in_flight, RT_PIPELINE)
     int tuneRefillLanes = 0, tuneExtendBlocks = 4;  // development knobs: RT_WF_REFILL (0: by scene size), RT_WF_BLOCKS
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
     int tuneWalkStop = 0, tuneWalkMin = 0;           // RT_WF_WALK_STOP (eighths), RT_WF_WALK_MIN: 0 = by scene size (WfParams::walkStop)

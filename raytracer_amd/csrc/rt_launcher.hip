@@ -209,13 +209,22 @@ size_t rt_image_pixel_bytes(int image) {
     }
 }
 
+int rt_frames_in_flight(const rt_ctx *c) { return c ? std::min(c->framesInFlight, c->lanesAvailable) : 0; }
+
 int rt_set_frames_in_flight(rt_ctx *c, int n) {
     if (!c) return RT_EINVAL;
-    if (n != 1 && n != 2) return fail(c, RT_EINVAL, "rt_set_frames_in_flight: 1 or 2");
+    if (n < 1 || n > RT_MAX_LANES) return fail(c, RT_EINVAL, "rt_set_frames_in_flight: 1 .. 4");
     int rc = bind(c);
     if (rc) return rc;
     if ((rc = rtJoinLanes(c))) return rc;
-    c->tunePipeline = n == 2;
+    n = std::min(n, c->lanesAvailable);
+    c->framesInFlight = n;
+    if (c->stream != c->ownStream && c->laneNow >= n) { // back to a lane that stays in use
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->stream = c->ownStream;
+        c->laneNow = 0;
+        c->chainValid = false;
+    }
     return RT_OK;
 }
 
@@ -234,14 +243,21 @@ int rt_create(int device_id, rt_ctx **out) {
     c->stream = c->ownStream;
     c->lane[0].stream = c->ownStream;
     // (a second lane that cannot be set up only means one frame at a time)
-    if (hipStreamCreateWithFlags(&c->lane[1].stream, hipStreamNonBlocking) != hipSuccess) c->lane[1].stream = nullptr;
-    for (rt_ctx::Lane &L : c->lane)
-        if (hipEventCreateWithFlags(&L.tick, hipEventDisableTiming) != hipSuccess) L.tick = nullptr;
-    if (!c->lane[0].tick || !c->lane[1].tick) {
-        if (c->lane[1].stream) (void)hipStreamDestroy(c->lane[1].stream);
-        c->lane[1].stream = nullptr;
+    int lanes = 1;
+    for (int k = 0; k < RT_MAX_LANES; ++k) {
+        rt_ctx::Lane &L = c->lane[k];
+        if (k && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) L.stream = nullptr;
+        if (L.stream && hipEventCreateWithFlags(&L.tick, hipEventDisableTiming) != hipSuccess) L.tick = nullptr;
+        if (k && (!L.stream || !L.tick)) break;
+        lanes = k + 1;
     }
-    if (const char *e = std::getenv("RT_PIPELINE")) c->tunePipeline = std::atoi(e) != 0;
+    if (!c->lane[0].tick) lanes = 1;
+    c->lanesAvailable = lanes;
+    c->framesInFlight = std::min(RT_DEFAULT_LANES, lanes);
+    if (const char *e = std::getenv("RT_PIPELINE")) { // 0 / 1: one frame at a time; n: n frames in flight
+        const int n = std::atoi(e);
+        c->framesInFlight = std::max(1, std::min(lanes, n <= 0 ? 1 : n));
+    }
     // Device address of the static scratch array on THIS device (each GPU holds its own copy): looked up once per
     // device, with that device current, and used from then on wherever host code needs the array's memory.
     if (device_id < RT_MAX_DEVICES && !rtStaticScratchPtr[device_id]) {
@@ -313,7 +329,8 @@ void rt_destroy(rt_ctx *c) {
         for (DevBuf *b : mine) releaseBuf(*b);
         if (L.tick) (void)hipEventDestroy(L.tick);
     }
-    if (c->lane[1].stream) (void)hipStreamDestroy(c->lane[1].stream);
+    for (int k = 1; k < RT_MAX_LANES; ++k)
+        if (c->lane[k].stream) (void)hipStreamDestroy(c->lane[k].stream);
     for (DevBuf *b : all) releaseBuf(*b);
     for (DevBuf &b : c->raw) releaseBuf(b);
     releaseBuf(c->cells);
@@ -794,16 +811,19 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         // copies them to the images — after waiting for everything queued before this call (the previous frame's
         // commit, the filter pass that reads its G-buffer, a gather's pack).  Not while the launcher still times its
         // schedule candidates, not with the per-pixel side images (written early), not on a caller's stream.
-        const bool ours = c->stream == c->lane[0].stream || c->stream == c->lane[1].stream;
+        bool ours = false;
+        for (int k = 0; k < c->lanesAvailable; ++k) ours = ours || c->stream == c->lane[k].stream;
+        const int lanes = std::min(c->framesInFlight, c->lanesAvailable);
         const size_t laneBytes = tilePixels * (size_t)n * rtWavefrontBytesPerPath();
-        const bool pipelined = c->tunePipeline && ours && c->lastWalkSettled && c->lane[1].stream &&
-                               !(p->flags & (RT_FLAG_AUX | RT_FLAG_PIXEL_STATS)) && laneBytes <= ((size_t)24 << 30);
+        const bool pipelined = lanes > 1 && ours && c->lastWalkSettled &&
+                               !(p->flags & (RT_FLAG_AUX | RT_FLAG_PIXEL_STATS)) &&
+                               laneBytes * (size_t)lanes <= ((size_t)48 << 30);
         hipEvent_t before = nullptr;
         if (pipelined) {
             rt_ctx::Lane &prev = c->lane[c->laneNow];
             HIP_TRY(c, hipEventRecord(prev.tick, c->stream));
             before = prev.tick;
-            c->laneNow ^= 1;
+            c->laneNow = (c->laneNow + 1) % lanes;
             c->stream = c->lane[c->laneNow].stream;
             c->chainValid = false;
         } else if ((rc = rtJoinLanes(c))) {

@@ -70,7 +70,7 @@ EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_uplo
            "rt_clear", "rt_trace", "rt_trace_batch", "rt_trace_batch_static", "rt_static_max_paths", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
            "rt_readback_rect_device", "rt_write_rect_device", "rt_write_rect_device_async", "rt_write_image", "rt_image_pixel_bytes",
            "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
-           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_gather_tiles", "rt_walk_stop", "rt_set_frames_in_flight",
+           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_gather_tiles", "rt_walk_stop", "rt_set_frames_in_flight", "rt_frames_in_flight",
            "rt_work_group_size", "rt_version"]
 
 _lib = None
@@ -121,6 +121,7 @@ def lib():
         L.rt_gather_tiles.argtypes = [vp, i32, rp, i32, i32]
         L.rt_walk_stop.argtypes = [vp]
         L.rt_set_frames_in_flight.argtypes = [vp, i32]
+        L.rt_frames_in_flight.argtypes = [vp]
         L.rt_work_group_size.argtypes = [i32, ctypes.POINTER(ctypes.c_int * 3)]
         L.rt_work_group_size.restype = None
         L.rt_version.restype = ctypes.c_char_p
@@ -302,8 +303,11 @@ class Context:
     def walk_stop(self):
         return int(lib().rt_walk_stop(self._h))
 
+    def frames_in_flight(self):
+        return int(lib().rt_frames_in_flight(self._h))
+
     def set_frames_in_flight(self, n):
-        """2 (default): successive frames alternate between two internal streams; 1: one frame at a time."""
+        """n > 1 (default 3): successive frames rotate over n internal streams; 1: one frame at a time."""
         self._check(lib().rt_set_frames_in_flight(self._h, int(n)), "rt_set_frames_in_flight")
 
     def readback(self, image):

@@ -401,6 +401,33 @@ def test_two_frames_in_flight_keep_their_images_apart(ctx):
     assert np.array_equal(got[50:300, 100:400].view(np.uint16), want_a[50:300, 100:400].view(np.uint16))
 
 
+def test_frames_in_flight_setting_does_not_change_the_images(ctx):
+    """rt_set_frames_in_flight(1 .. 4): a run of frames that accumulate onto each other (blendFactor k/(k+1) across
+    calls, as the reference's main loop does), each followed by a filter, gives the same colour, G-buffer and filtered
+    image whatever the number of lanes."""
+    w, h = 480, 270
+    wl = workloads.Workload("scene", w, h)
+    ctx.upload_scene(wl.buffers)
+    ctx.resize(w, h)
+    results = {}
+    for lanes in (1, 2, 3, 4):
+        ctx.set_frames_in_flight(lanes)
+        assert ctx.frames_in_flight() == lanes
+        ctx.clear()
+        for k in range(7):  # 7 calls of 2 samples: sample index keeps counting, so every call blends onto the last
+            ctx.trace_samples(wl.rays, wl.eye, spp=2, frame0=2 * k, max_bounces=4, num_emitters=wl.num_emitters)
+            ctx.filter(3)
+        results[lanes] = {k: ctx.readback(v).copy() for k, v in
+                          dict(color=hiplib.IMAGE_COLOR, normal=hiplib.IMAGE_NORMAL, pos=hiplib.IMAGE_POSITION,
+                               filtered=hiplib.IMAGE_FILTERED).items()}
+    ctx.set_frames_in_flight(3)
+    with pytest.raises(hiplib.RtError):
+        ctx.set_frames_in_flight(5)
+    for lanes in (2, 3, 4):
+        for k, v in results[lanes].items():
+            assert np.array_equal(v.view(np.uint8), results[1][k].view(np.uint8)), (lanes, k)
+
+
 def test_weighted_lights_flag(ctx):
     """RT_FLAG_WEIGHTED_LIGHTS: the emitter pick of the block the reference keeps commented out (random.glsl:223-248),
     against the llvmpipe fixture made with that block enabled, against the oracle on scenes where the block's
