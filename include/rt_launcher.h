@@ -282,6 +282,19 @@ int rt_walk_stop(const rt_ctx *ctx);
 int rt_set_frames_in_flight(rt_ctx *ctx, int n);
 int rt_frames_in_flight(const rt_ctx *ctx);
 
+/* Flat cells (no counterpart in the reference).  The wavefront pipeline's last kernel records which 16 x 16 pixel cells
+ * of its tile it left with ONE texel (colour, normal and position equal bit for bit: the sky behind a scene).  rt_filter
+ * derives from that, per cell, the number of passes ("level") whose result for the cell's pixels depends on texels of
+ * one value only, computes those results once per cell, and each pass stores them for the tiles made of such cells
+ * instead of filtering texel by texel.  The images are bit for bit what they are without the record (RT_FILTER_CELLS=0
+ * at rt_create turns it off); it is dropped whenever anything else writes colour, normals or positions, and not used by
+ * an rt_filter that reads beyond the tile of the frame that made it.  rt_flat_cells copies it for inspection (blocking):
+ * which = 0, the flags (1 = flat) the last wavefront frame left; which = 1, the levels the last rt_filter used;
+ * out[cy * ((width + 15) / 16) + cx], nbytes = ((width + 15) / 16) * ((height + 15) / 16); cells outside the frame's
+ * tile hold older entries.  RT_ESTATE when there is no such record (none made yet, dropped, or not usable by the last
+ * rt_filter). */
+int rt_flat_cells(rt_ctx *ctx, int which, uint8_t *flags, size_t nbytes);
+
 int rt_counters_read(rt_ctx *ctx, rt_counters *out); /* blocking */
 int rt_counters_reset(rt_ctx *ctx);
 int rt_profile(rt_ctx *ctx, int enable);             /* HIP-event timing of every launch */

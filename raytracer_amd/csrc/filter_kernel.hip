@@ -46,6 +46,79 @@ __device__ __forceinline__ float divUniform(float x, float d, float rd) {
     return __fmaf_rn(__fmaf_rn(-q, d, x), rd, q);
 }
 
+struct PassScalars { // per-pass constants of atrous.fs's uniforms and their reciprocals
+    float c_phi, n_phi, p_phi, stepsq, r_c, r_n, r_p, r_s;
+};
+__device__ __forceinline__ PassScalars passScalars(float c_phi, float n_phi, float p_phi, int step) {
+    PassScalars k;
+    k.c_phi = c_phi, k.n_phi = n_phi, k.p_phi = p_phi, k.stepsq = (float)(step * step);
+    k.r_c = 1.0f / c_phi, k.r_n = 1.0f / n_phi, k.r_p = 1.0f / p_phi, k.r_s = 1.0f / k.stepsq;
+    return k;
+}
+
+// One pixel of a pass: atrous.fs::main (:19-53) over the nine taps `tap(oy, ox, colour, normal, position)` hands out
+// (already unpacked; colour.x = NaN marks a tap the shader skips).  Both the staged path and the flat-cell path go
+// through this one function, so a neighbourhood of nine equal texels gives the same bits either way.
+template <class Tap>
+__device__ __forceinline__ uint2 atrousPixel(const float4 cval, const float4 nval, const float4 pval, const PassScalars k,
+                                             Tap tap) {
+    float4 sum = make_float4(0, 0, 0, 0);
+    float cum_w = 0.0f;
+#pragma unroll
+    for (int oy = -1; oy <= 1; oy++) {
+#pragma unroll
+        for (int ox = -1; ox <= 1; ox++) { // offsets in the order of filter.cpp:28-34
+            float4 ctmp, n, ptap;
+            tap(oy, ox, ctmp, n, ptap);
+            if (ctmp.x != ctmp.x) continue; // atrous.fs:35-38 (a NaN in any channel: marked while staging)
+            // kernel weight by |ox|+|oy| (filter.cpp:41-43): 2 -> 1/16, 1 -> 1/8, 0 -> 1/4.  Powers of two, so
+            // (c * w) * k of the shader equals c * (w * k) bit for bit.
+            float wk = (ox != 0 && oy != 0) ? 1.0f / 16 : (ox != 0 || oy != 0) ? 1.0f / 8 : 1.0f / 4;
+            if (ox != 0 || oy != 0) { // (the centre tap: all three distances are 0, or NaN which the min drops: weight 1)
+                float4 t = sub4(cval, ctmp);
+                // c_w * n_w * p_w = min(exp(a),1) * min(exp(b),1) * min(exp(c),1) with a, b, c <= 0 (or NaN, for which
+                // the oracle's min returns 1): formed as ONE exp(a + b + c) with NaN arguments replaced by 0.  Same value up
+                // to the rounding of two products (about 1e-7 relative; the result is stored as fp16), a third of the
+                // transcendental work.  The exponential is the hardware's (v_exp_f32 on x * log2 e, about 2 ulp): the
+                // oracle platform's own exp is a polynomial that differs from libm's as much, and against its fixtures
+                // the fp16 outputs stay >= 99.9 % identical, the rest one fp16 step (scripts/filter_margin.py).
+                const float a = fminf(divUniform(-dot4(t, t), k.c_phi, k.r_c), 0.0f);
+                const float dx = nval.x - n.x, dy = nval.y - n.y, dz = nval.z - n.z; // (w - w = 0 adds exactly nothing)
+                const float dist2 = fmaxf(divUniform(dx * dx + (dy * dy + dz * dz), k.stepsq, k.r_s), 0.0f);
+                const float b = fminf(divUniform(-dist2, k.n_phi, k.r_n), 0.0f);
+                t = sub4(pval, ptap);
+                const float c = fminf(divUniform(-dot4(t, t), k.p_phi, k.r_p), 0.0f);
+                wk *= __expf((a + b) + c);
+            }
+            sum.x += ctmp.x * wk;
+            sum.y += ctmp.y * wk;
+            sum.z += ctmp.z * wk;
+            sum.w += ctmp.w * wk;
+            cum_w += wk;
+        }
+    }
+    // sum / cum_w (atrous.fs:52): four quotients by one divisor -> one reciprocal + the correction step of divUniform
+    // (the correctly rounded quotient for finite, non-zero cum_w; a pixel all of whose taps were skipped divides as written)
+    float4 q;
+    if (cum_w > 0.0f && cum_w < __builtin_inff()) {
+        const float r = 1.0f / cum_w;
+        q = make_float4(divUniform(sum.x, cum_w, r), divUniform(sum.y, cum_w, r), divUniform(sum.z, cum_w, r),
+                        divUniform(sum.w, cum_w, r));
+    } else {
+        q = make_float4(sum.x / cum_w, sum.y / cum_w, sum.z / cum_w, sum.w / cum_w);
+    }
+    return make_uint2(pack_half2_rtz(q.x, q.y), pack_half2_rtz(q.z, q.w));
+}
+
+// a texel as the taps see it: colour with the NaN mark, normal and position unpacked
+__device__ __forceinline__ void unpackTexel(bool f32, float4 c32, uint2 c16, uint32_t n, uint2 ph, float4 &c, float4 &nv,
+                                            float4 &pv) {
+    c = f32 ? c32 : unpackHalf4(c16);
+    if (c.x != c.x || c.y != c.y || c.z != c.z || c.w != c.w) c.x = __builtin_nanf("");
+    nv = unpackSnorm4(n);
+    pv = unpackHalf4(ph); // (a texel outside the image: zeros, like texelFetch on the oracle)
+}
+
 } // namespace
 
 // colorF32 != nullptr: pass 0 (reads the RGBA32F accumulation image); else reads colorF16.
@@ -57,8 +130,9 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
                                                         const uint32_t *__restrict__ normal,
                                                         const uint2 *__restrict__ pos, uint2 *__restrict__ out, int W,
                                                         int H, rt_rect rect, int tilesX, float c_phi, float n_phi,
-                                                        float p_phi, int step) {
+                                                        float p_phi, int step, RtFilterCells cells) {
     static_assert(TX * TY == 256, "one pixel per thread");
+    static_assert((TX / 16 + 1) * ((TY + 14) / 16 + 1) <= 256, "one thread per cell a tile can touch");
     extern __shared__ __align__(16) unsigned char lds[];
     const int cols = TX + 2 * step;
     const int rows = BANDS ? 3 * TY : TY + 2 * step;
@@ -66,8 +140,28 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
     float4 *sNrm = sCol + rows * cols;                // normal xyz as fp32 (w of the stored normals is always 0)
     float4 *sPos = sNrm + rows * cols;                // position xyzw as fp32
 
-    const int tileId = blockIdx.x;
-    const int x0 = rect.x0 + (tileId % tilesX) * TX, y0 = rect.y0 + (tileId / tilesX) * TY;
+    // Consecutive blocks go to consecutive XCDs.  With as many tiles per row as XCDs (256-pixel tiles, 1920 pixels) a
+    // plain row-major order would hand one XCD every tile of a column — all of the image's left edge, say, none of
+    // which can use the flat-cell results while most tiles of other columns can: the columns are rotated row by row.
+    const int tileRow = (int)blockIdx.x / tilesX;
+    const int tileCol = ((int)blockIdx.x % tilesX + tileRow) % tilesX;
+    const int x0 = rect.x0 + tileCol * TX, y0 = rect.y0 + tileRow * TY;
+    const PassScalars ks = passScalars(c_phi, n_phi, p_phi, step);
+    // Flat cells (rt_device.h): a tile all of whose cells have this pass's result per cell stores those and is done.
+    if (cells.level) {
+        const int xe = min(x0 + TX, rect.x1), ye = min(y0 + TY, rect.y1);
+        const int cxa = x0 >> RT_CELL_SHIFT, cya = y0 >> RT_CELL_SHIFT;
+        const int ncx = ((xe - 1) >> RT_CELL_SHIFT) - cxa + 1, ncy = ((ye - 1) >> RT_CELL_SHIFT) - cya + 1;
+        int mine = 1;
+        if ((int)threadIdx.x < ncx * ncy)
+            mine = cells.level[(cya + (int)threadIdx.x / ncx) * cells.cellsX + cxa + (int)threadIdx.x % ncx] > cells.pass;
+        if (__syncthreads_and(mine)) {
+            const int x = x0 + (int)threadIdx.x % TX, y = y0 + (int)threadIdx.x / TX;
+            if (x < rect.x1 && y < rect.y1)
+                out[(size_t)y * W + x] = cells.texel[(y >> RT_CELL_SHIFT) * cells.cellsX + (x >> RT_CELL_SHIFT)];
+            return;
+        }
+    }
 
     // Staging in two sweeps: first every global load of this thread's texels is issued (one trip to memory for all of
     // them: large steps leave room for few blocks per CU, so the latency is not hidden by other blocks), then they
@@ -100,12 +194,11 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
     for (int k = 0; k < kMaxTexels; ++k) {
         const int e = threadIdx.x + 256 * k;
         if (e < rows * cols) {
-            float4 c = colorF32 ? cv[k] : unpackHalf4(cvh[k]);
-            if (c.x != c.x || c.y != c.y || c.z != c.z || c.w != c.w) c.x = __builtin_nanf("");
-            const uint32_t n = nvr[k];
+            float4 c, nv, pv;
+            unpackTexel(colorF32 != nullptr, cv[k], cvh[k], nvr[k], pvh[k], c, nv, pv);
             sCol[e] = c;
-            sNrm[e] = make_float4(snorm8_to_float(n), snorm8_to_float(n >> 8), snorm8_to_float(n >> 16), snorm8_to_float(n >> 24));
-            sPos[e] = unpackHalf4(pvh[k]); // (a texel outside the image: zeros, like texelFetch on the oracle)
+            sNrm[e] = nv;
+            sPos[e] = pv;
         }
     }
     __syncthreads();
@@ -116,59 +209,109 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
 
     const int rowStride = BANDS ? TY * cols : step * cols; // from a tap row to the next
     const int centre = (BANDS ? TY + ly : ly + step) * cols + step + lx;
-    const float4 cval = sCol[centre];
-    const float4 nval = sNrm[centre];
-    const float4 pval = sPos[centre];
-    const float stepsq = (float)(step * step);
-    const float r_c = 1.0f / c_phi, r_n = 1.0f / n_phi, r_p = 1.0f / p_phi, r_s = 1.0f / stepsq;
+    out[(size_t)y * W + x] = atrousPixel(sCol[centre], sNrm[centre], sPos[centre], ks,
+                                         [&](int oy, int ox, float4 &c, float4 &n, float4 &p) {
+                                             const int e = centre + oy * rowStride + ox * step;
+                                             c = sCol[e];
+                                             n = sNrm[e];
+                                             p = sPos[e];
+                                         });
+}
 
-    float4 sum = make_float4(0, 0, 0, 0);
-    float cum_w = 0.0f;
+// Flat cells: from the record the blend kernel left (rec), the level of every cell and the per-cell results of the
+// passes below it.  Pass i (step 2^(i+1) - 1) of a pixel reads texels up to S_i = step_0 + ... + step_i pixels away
+// through the passes before it.  Cell C has level > i when every cell that holds such a texel for one of C's pixels —
+// the cells within ceil(S_i / 16) of C — is flat, all with one texel, and none of those texels lies outside the image
+// (those read as zero).  Every pixel of C then sees nine equal taps in every pass up to i, and its results are the
+// chain texel_0 -> atrousPixel -> texel_1 -> ... computed here once per cell by the very function the passes use.
+// "All with one texel" is checked on neighbouring pairs: a cell is GOOD when it is flat and equal to its flat right
+// and upper neighbours; a window of good cells has all its neighbouring pairs equal, hence one texel.
+// Entries of the record outside the frame's tile may be stale: they can only lower a level, never make a wrong one,
+// as long as everything the first pass reads lies inside that tile (rt_filter checks this) — the texels a result
+// really depends on are then all in cells the frame wrote.
+#define FL_MAXR 8 // cells: ceil((1 + 3 + 7 + 15 + 31 + 63) / 16)
+struct FlatPasses {
+    float c_phi[RT_FLAT_MAX_PASSES], n_phi[RT_FLAT_MAX_PASSES], p_phi[RT_FLAT_MAX_PASSES];
+    int passes;
+};
+
+__device__ __forceinline__ bool sameTexel(const RtFlatCells &rec, int a, int b) {
+    const float4 ca = rec.color[a], cb = rec.color[b];
+    const uint2 pa = rec.pos[a], pb = rec.pos[b];
+    return __float_as_uint(ca.x) == __float_as_uint(cb.x) && __float_as_uint(ca.y) == __float_as_uint(cb.y) &&
+           __float_as_uint(ca.z) == __float_as_uint(cb.z) && __float_as_uint(ca.w) == __float_as_uint(cb.w) &&
+           rec.normal[a] == rec.normal[b] && pa.x == pb.x && pa.y == pb.y;
+}
+
+__global__ __launch_bounds__(256) void rt_flat_levels_kernel(RtFlatCells rec, uint8_t *__restrict__ level,
+                                                             uint2 *__restrict__ texels, int W, int H, FlatPasses pp) {
+    constexpr int SIDE = 16 + 2 * FL_MAXR;
+    __shared__ uint8_t sGood[SIDE * SIDE];
+    const int patchesX = (rec.cellsX + 15) / 16;
+    const int pcx = ((int)blockIdx.x % patchesX) * 16, pcy = ((int)blockIdx.x / patchesX) * 16;
+    // (every load of a thread's cells is issued before the first is used: one trip to memory, not one per cell)
+    constexpr int PER = (SIDE * SIDE + 255) / 256;
+    bool inside[PER];
+    int at[PER], right[PER], up[PER];
+    uint8_t f0[PER], fr[PER], fu[PER];
 #pragma unroll
-    for (int oy = -1; oy <= 1; oy++) {
+    for (int k = 0; k < PER; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const int cx = pcx - FL_MAXR + e % SIDE, cy = pcy - FL_MAXR + e / SIDE;
+        inside[k] = e < SIDE * SIDE && cx >= 0 && cy >= 0 && cx < rec.cellsX && cy < rec.cellsY;
+        const int ccx = min(max(cx, 0), rec.cellsX - 1), ccy = min(max(cy, 0), rec.cellsY - 1);
+        at[k] = ccy * rec.cellsX + ccx;
+        right[k] = ccx + 1 < rec.cellsX ? at[k] + 1 : at[k];
+        up[k] = ccy + 1 < rec.cellsY ? at[k] + rec.cellsX : at[k];
+        f0[k] = rec.flag[at[k]];
+        fr[k] = rec.flag[right[k]];
+        fu[k] = rec.flag[up[k]];
+    }
+    bool eqR[PER], eqU[PER]; // (texels of cells that are not flat are older entries: the flags decide whether they count)
 #pragma unroll
-        for (int ox = -1; ox <= 1; ox++) { // offsets in the order of filter.cpp:28-34
-            const int e = centre + oy * rowStride + ox * step;
-            const float4 ctmp = sCol[e];
-            if (ctmp.x != ctmp.x) continue; // atrous.fs:35-38 (a NaN in any channel: marked while staging)
-            // kernel weight by |ox|+|oy| (filter.cpp:41-43): 2 -> 1/16, 1 -> 1/8, 0 -> 1/4.  Powers of two, so
-            // (c * w) * k of the shader equals c * (w * k) bit for bit.
-            float wk = (ox != 0 && oy != 0) ? 1.0f / 16 : (ox != 0 || oy != 0) ? 1.0f / 8 : 1.0f / 4;
-            if (ox != 0 || oy != 0) { // (the centre tap: all three distances are 0, or NaN which the min drops: weight 1)
-                float4 t = sub4(cval, ctmp);
-                // c_w * n_w * p_w = min(exp(a),1) * min(exp(b),1) * min(exp(c),1) with a, b, c <= 0 (or NaN, for which
-                // the oracle's min returns 1): formed as ONE exp(a + b + c) with NaN arguments replaced by 0.  Same value up
-                // to the rounding of two products (about 1e-7 relative; the result is stored as fp16), a third of the
-                // transcendental work.  The exponential is the hardware's (v_exp_f32 on x * log2 e, about 2 ulp): the
-                // oracle platform's own exp is a polynomial that differs from libm's as much, and against its fixtures
-                // the fp16 outputs stay >= 99.9 % identical, the rest one fp16 step (scripts/filter_margin.py).
-                const float a = fminf(divUniform(-dot4(t, t), c_phi, r_c), 0.0f);
-                const float4 n = sNrm[e];
-                const float dx = nval.x - n.x, dy = nval.y - n.y, dz = nval.z - n.z; // (w - w = 0 adds exactly nothing)
-                const float dist2 = fmaxf(divUniform(dx * dx + (dy * dy + dz * dz), stepsq, r_s), 0.0f);
-                const float b = fminf(divUniform(-dist2, n_phi, r_n), 0.0f);
-                t = sub4(pval, sPos[e]);
-                const float c = fminf(divUniform(-dot4(t, t), p_phi, r_p), 0.0f);
-                wk *= __expf((a + b) + c);
-            }
-            sum.x += ctmp.x * wk;
-            sum.y += ctmp.y * wk;
-            sum.z += ctmp.z * wk;
-            sum.w += ctmp.w * wk;
-            cum_w += wk;
-        }
+    for (int k = 0; k < PER; ++k) {
+        eqR[k] = sameTexel(rec, at[k], right[k]);
+        eqU[k] = sameTexel(rec, at[k], up[k]);
     }
-    // sum / cum_w (atrous.fs:52): four quotients by one divisor -> one reciprocal + the correction step of divUniform
-    // (the correctly rounded quotient for finite, non-zero cum_w; a pixel all of whose taps were skipped divides as written)
-    float4 q;
-    if (cum_w > 0.0f && cum_w < __builtin_inff()) {
-        const float r = 1.0f / cum_w;
-        q = make_float4(divUniform(sum.x, cum_w, r), divUniform(sum.y, cum_w, r), divUniform(sum.z, cum_w, r),
-                        divUniform(sum.w, cum_w, r));
-    } else {
-        q = make_float4(sum.x / cum_w, sum.y / cum_w, sum.z / cum_w, sum.w / cum_w);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        const bool good = inside[k] && f0[k] && (!fr[k] || eqR[k]) && (!fu[k] || eqU[k]);
+        if (e < SIDE * SIDE) sGood[e] = good ? 1 : 0;
     }
-    out[(size_t)y * W + x] = make_uint2(pack_half2_rtz(q.x, q.y), pack_half2_rtz(q.z, q.w));
+    __syncthreads();
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int cx = pcx + lx, cy = pcy + ly;
+    if (cx >= rec.cellsX || cy >= rec.cellsY) return;
+    const int cell = cy * rec.cellsX + cx;
+    const int px = cx << RT_CELL_SHIFT, py = cy << RT_CELL_SHIFT;
+    int lvl = 0, reach = 0;
+    for (int i = 0; i < pp.passes; ++i) {
+        reach += (2 << i) - 1;
+        if (px - reach < 0 || py - reach < 0 || px + 15 + reach >= W || py + 15 + reach >= H) break;
+        const int R = (reach + 15) >> RT_CELL_SHIFT;
+        unsigned all = 1;
+        for (int dy = -R; dy <= R; ++dy)
+            for (int dx = -R; dx <= R; ++dx) all &= sGood[(ly + FL_MAXR + dy) * SIDE + lx + FL_MAXR + dx];
+        if (!all) break;
+        lvl = i + 1;
+    }
+    level[cell] = (uint8_t)lvl;
+    if (lvl == 0) return;
+    float4 c, nv, pv;
+    unpackTexel(true, rec.color[cell], make_uint2(0, 0), rec.normal[cell], rec.pos[cell], c, nv, pv);
+    const size_t cells = (size_t)rec.cellsX * rec.cellsY;
+    for (int i = 0; i < lvl; ++i) {
+        const PassScalars ks = passScalars(pp.c_phi[i], pp.n_phi[i], pp.p_phi[i], (2 << i) - 1);
+        const uint2 t = atrousPixel(c, nv, pv, ks, [&](int, int, float4 &tc, float4 &tn, float4 &tp) {
+            tc = c;
+            tn = nv;
+            tp = pv;
+        });
+        texels[(size_t)i * cells + cell] = t;
+        float4 unusedN, unusedP;
+        unpackTexel(false, make_float4(0, 0, 0, 0), t, 0u, make_uint2(0, 0), c, unusedN, unusedP);
+    }
 }
 
 // quad.fs:10-22: mapped = 1 - exp(-hdr * exposure); pow(mapped, 1/2.2); alpha 1; 8-bit unorm store.
@@ -197,9 +340,25 @@ __global__ __launch_bounds__(256) void rt_tonemap_kernel(const float4 *__restric
 
 int rtAtrousMaxStep() { return FT_MAXSTEP; }
 
+// level: one byte per cell; texels: RT_FLAT_MAX_PASSES planes of one uint2 per cell; phis: c_phi, n_phi, p_phi per pass
+hipError_t rtLaunchFlatLevels(const RtFlatCells &rec, uint8_t *level, uint2 *texels, int W, int H, int passes,
+                              const float *c_phi, const float *n_phi, const float *p_phi, hipStream_t stream) {
+    if (passes < 1 || passes > RT_FLAT_MAX_PASSES) return hipErrorInvalidValue;
+    FlatPasses pp;
+    pp.passes = passes;
+    for (int i = 0; i < RT_FLAT_MAX_PASSES; ++i) {
+        pp.c_phi[i] = i < passes ? c_phi[i] : 1.0f;
+        pp.n_phi[i] = i < passes ? n_phi[i] : 1.0f;
+        pp.p_phi[i] = i < passes ? p_phi[i] : 1.0f;
+    }
+    const int patches = ((rec.cellsX + 15) / 16) * ((rec.cellsY + 15) / 16);
+    hipLaunchKernelGGL(rt_flat_levels_kernel, dim3(patches), dim3(256), 0, stream, rec, level, texels, W, H, pp);
+    return hipGetLastError();
+}
+
 hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const uint32_t *normal, const uint2 *pos,
                           uint2 *out, int W, int H, const rt_rect &rect, float c_phi, float n_phi, float p_phi,
-                          int step, hipStream_t stream) {
+                          int step, const RtFilterCells &cells, hipStream_t stream) {
     const int rw = rect.x1 - rect.x0, rh = rect.y1 - rect.y0;
     if (rw <= 0 || rh <= 0) return hipSuccess;
     // tile shape by step width: the fewest staged texels per output pixel (48 bytes of LDS each)
@@ -207,7 +366,7 @@ hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const u
         const int tilesX = (rw + TX - 1) / TX, tilesY = (rh + TY - 1) / TY;
         const size_t ldsBytes = (size_t)(bands ? 3 * TY : TY + 2 * step) * (TX + 2 * step) * 48;
         hipLaunchKernelGGL(kernel, dim3(tilesX * tilesY), dim3(256), ldsBytes, stream, colorF32, colorF16, normal, pos,
-                           out, W, H, rect, tilesX, c_phi, n_phi, p_phi, step);
+                           out, W, H, rect, tilesX, c_phi, n_phi, p_phi, step, cells);
     };
     if (step <= 2) launch(rt_atrous_kernel<16, 16, false>, 16, 16, false);
     else if (step <= 4) launch(rt_atrous_kernel<32, 8, false>, 32, 8, false);

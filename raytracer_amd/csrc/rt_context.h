@@ -46,6 +46,15 @@ struct rt_ctx {
     int width = 0, height = 0;
     DevBuf color, normal, pos, filt[2], tridx, visits, stats, ldr;
     int filteredIndex = -1; // which of filt[] holds the result of the last rt_filter
+    // Flat cells (rt_device.h: RtFlatCells).  flatFlag / flatColor / flatNormal / flatPos: what the last wavefront
+    // frame's blend kernel recorded; flatLevel / flatTexels: what the last rt_filter derived from it (levels and the
+    // per-cell results of its passes).  flatValid: the record describes colour, normals and positions as they are
+    // now inside flatRect (the tile of the frame that made it) — cleared by every other writer of those images.
+    // useFlatCells: RT_FILTER_CELLS=0 turns the shortcut off (the images are the same either way; tests compare the two).
+    DevBuf flatFlag, flatColor, flatNormal, flatPos, flatLevel, flatTexels;
+    bool flatValid = false, useFlatCells = true;
+    bool filterUsedFlat = false; // the last rt_filter ran with the record (flatLevel then belongs to the filtered image)
+    rt_rect flatRect = {0, 0, 0, 0};
 
     // wavefront path tracer state (wavefront.h), grown on demand
     // Wavefront pipeline memory, one set per LANE.  Two frames may be in flight: successive rt_trace_batch calls

@@ -82,6 +82,30 @@ struct RtImages {
     int width, height;
 };
 
+// Flat cells.  The image is divided into 16 x 16 pixel cells (cell (cx, cy) = pixels 16 cx .. 16 cx + 15 of rows
+// 16 cy .. 16 cy + 15).  A cell is FLAT when all its texels are equal bit for bit in colour, normal and position (the
+// sky behind a scene: trace3.cs:639-647 writes one constant there).  The wavefront pipeline's blend kernel, the one
+// kernel that commits a frame's colour, records which cells it left flat and their texel.  rt_filter turns the record
+// into a LEVEL per cell — the number of filter passes whose result for every pixel of the cell depends on texels of
+// one value only — and the results themselves (filter_kernel.hip: rt_flat_levels_kernel); a pass stores those results
+// for the tiles whose cells all have them instead of staging and filtering texel by texel.  The launcher keeps track
+// of whether the record still describes the images (rt_launcher.hip: flatValid).
+#define RT_CELL_SHIFT 4
+#define RT_FLAT_MAX_PASSES 6
+struct RtFlatCells {
+    uint8_t *flag;      // [cellsY][cellsX]; null: no record is kept
+    float4 *color;      // the texel of a flat cell: RGBA32F colour,
+    uint32_t *normal;   // packed normal,
+    uint2 *pos;         // packed position
+    int cellsX, cellsY;
+};
+// What one filter pass reads of it.  level null: the pass filters every texel.
+struct RtFilterCells {
+    const uint8_t *level;   // [cellsY][cellsX] passes 0 .. level-1 of this rt_filter call have a per-cell result
+    const uint2 *texel;     // [cellsY][cellsX] this pass's result for the cells with level > pass
+    int cellsX, pass;
+};
+
 // Global counters are sharded: every wave adds to the shard its block/wave number selects, each shard
 // on a 128-byte line of its own, and rt_counters_read sums the shards.  One word shared by every wave
 // of a launch serialises at the memory side (measured: ~88 atomics/us on one address, which cost the

@@ -25,9 +25,11 @@ struct rt_ctx;
 void rtMarkKernel(void *ctxOpaque, int kind, bool begin);
 hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const uint32_t *normal, const uint2 *pos,
                           uint2 *out, int W, int H, const rt_rect &rect, float c_phi, float n_phi, float p_phi,
-                          int step, hipStream_t stream);
+                          int step, const RtFilterCells &cells, hipStream_t stream);
 hipError_t rtLaunchTonemap(const float4 *colorF32, const uint2 *colorF16, uint32_t *out, int W, const rt_rect &rect,
                            float exposure, hipStream_t stream);
+hipError_t rtLaunchFlatLevels(const RtFlatCells &rec, uint8_t *level, uint2 *texels, int W, int H, int passes,
+                              const float *c_phi, const float *n_phi, const float *p_phi, hipStream_t stream);
 int rtAtrousMaxStep();
 // rt_comm.hip
 void rtCommQuiesce(rt_ctx *c);
@@ -276,6 +278,7 @@ int rt_create(int device_id, rt_ctx **out) {
         delete c;
         return RT_ENOMEM;
     }
+    if (const char *e = std::getenv("RT_FILTER_CELLS")) c->useFlatCells = std::atoi(e) != 0;
     if (const char *e = std::getenv("RT_WF_REFILL")) c->tuneRefillLanes = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_CACHE_NODES")) c->tuneCacheNodes = std::max(0, std::min(3800, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_RAYS_PER_WAVE")) c->tuneRaysPerWave = std::max(0, std::min(64, std::atoi(e)));
@@ -321,7 +324,7 @@ void rt_destroy(rt_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     DevBuf *all[] = {&c->boxes, &c->leaves, &c->tris48, &c->tris128, &c->mtls, &c->emitters, &c->color, &c->normal,
                      &c->pos, &c->filt[0], &c->filt[1], &c->tridx, &c->visits, &c->stats, &c->ldr, &c->counters,
-                     &c->spec};
+                     &c->spec, &c->flatFlag, &c->flatColor, &c->flatNormal, &c->flatPos, &c->flatLevel, &c->flatTexels};
     for (rt_ctx::Lane &L : c->lane) {
         for (DevBuf &b : L.wfState) releaseBuf(b);
         for (DevBuf &b : L.wfRay) releaseBuf(b);
@@ -526,6 +529,8 @@ int rt_clear(rt_ctx *c) {
     HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, n * 16, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->ldr.p, 0, n * 4, c->stream));
     c->filteredIndex = -1;
+    c->flatValid = false;
+    c->filterUsedFlat = false;
     return RT_OK;
 }
 
@@ -544,6 +549,11 @@ int rt_resize(rt_ctx *c, int width, int height) {
     if ((r = ensure(c, c->color, n * 16)) || (r = ensure(c, c->normal, n * 4)) || (r = ensure(c, c->pos, n * 8)) ||
         (r = ensure(c, c->filt[0], n * 8)) || (r = ensure(c, c->filt[1], n * 8)) || (r = ensure(c, c->tridx, n * 4)) ||
         (r = ensure(c, c->visits, n * 4)) || (r = ensure(c, c->stats, n * 16)) || (r = ensure(c, c->ldr, n * 4)))
+        return r;
+    const size_t cellCount = (size_t)((width + 15) >> RT_CELL_SHIFT) * (size_t)((height + 15) >> RT_CELL_SHIFT);
+    if ((r = ensure(c, c->flatFlag, cellCount)) || (r = ensure(c, c->flatColor, cellCount * 16)) ||
+        (r = ensure(c, c->flatNormal, cellCount * 4)) || (r = ensure(c, c->flatPos, cellCount * 8)) ||
+        (r = ensure(c, c->flatLevel, cellCount)) || (r = ensure(c, c->flatTexels, cellCount * 8 * RT_FLAT_MAX_PASSES)))
         return r;
     c->walkTune.state = 0;
     c->walkTune.pending = false;
@@ -623,6 +633,7 @@ int ensureWavefront(rt_ctx *c, rt_ctx::Lane &L, size_t capacity, size_t radiance
     wf.primPix = (unsigned *)L.wfPrimPix.p;
     wf.stageNormal = nullptr;
     wf.stagePos = nullptr;
+    wf.flat = RtFlatCells{};
     wf.capacity = (int)L.wfCapacity;
     return RT_OK;
 }
@@ -795,6 +806,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
                               tilePixels * (size_t)n > ((size_t)1 << 30);
         if (perPixel) {
             if ((rc = rtJoinLanes(c))) return rc;
+            c->flatValid = false;
             for (int k = 0; k < n; ++k) {
                 SpanGuard span(c, TK_TRACE), span2(c, RT_TIME_PER_PIXEL);
                 rt_trace_params pk = params[k];
@@ -838,10 +850,25 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             wf.stageNormal = (uint32_t *)L.stageNormal.p;
             wf.stagePos = (uint2 *)L.stagePos.p;
         }
-        return wavefrontFrame(c, params, n, r, sc, img, wf, false, before);
+        if (c->useFlatCells && c->flatFlag.p) {
+            wf.flat.flag = (uint8_t *)c->flatFlag.p;
+            wf.flat.color = (float4 *)c->flatColor.p;
+            wf.flat.normal = (uint32_t *)c->flatNormal.p;
+            wf.flat.pos = (uint2 *)c->flatPos.p;
+            wf.flat.cellsX = (c->width + 15) >> RT_CELL_SHIFT;
+            wf.flat.cellsY = (c->height + 15) >> RT_CELL_SHIFT;
+        }
+        c->flatValid = false;
+        rc = wavefrontFrame(c, params, n, r, sc, img, wf, false, before);
+        if (rc == RT_OK && wf.flat.flag) { // the record covers this frame's tile (cells outside it keep older entries)
+            c->flatValid = true;
+            c->flatRect = r;
+        }
+        return rc;
     }
     case RT_KERNEL_TRACE3_RL: {
         if ((rc = rtJoinLanes(c))) return rc;
+        c->flatValid = false;
         // traceRL (reference trace3.cs:695-791): the scene of trace3 plus the Q-table state of slots 7..10.
         if (!c->boxes.p || !c->tris48.p || !c->mtls.p)
             return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
@@ -886,6 +913,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     }
     case RT_KERNEL_TRACE: case RT_KERNEL_TRACE1: case RT_KERNEL_TRACE2: {
         if ((rc = rtJoinLanes(c))) return rc;
+        c->flatValid = false;
         // The analytic-scene kernels: no scene buffers; trace1 reads the blue-noise tables when useBlueNoise is
         // set, trace2 the two LTC look-up tables (reference src/Tracer.cpp:23-90).
         if (p->kernel == RT_KERNEL_TRACE1 && p->useBlueNoise &&
@@ -997,6 +1025,8 @@ int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const
     wf.rayWork = (int2 *)take(kStaticRay8);
     wf.stageNormal = nullptr;
     wf.stagePos = nullptr;
+    wf.flat = RtFlatCells{};
+    c->flatValid = false;
     wf.queue[0] = (int *)take(kStaticQueue);
     wf.queue[1] = (int *)take(kStaticQueue);
     wf.primPix = (unsigned *)take(kStaticQueue);
@@ -1030,6 +1060,38 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
     const float4 *readF32 = (const float4 *)c->color.p;
     const uint2 *readF16 = nullptr;
     int write = 0;
+    // Flat cells (rt_device.h): usable when the record the last wavefront frame left still describes the images
+    // everywhere this call reads (the target grown by the filter's halo, inside the image).  One small launch turns
+    // it into the level of every cell and the per-cell results of the passes.
+    bool flat = c->useFlatCells && c->flatValid && c->flatFlag.p && iterations > 0 && iterations <= RT_FLAT_MAX_PASSES;
+    if (flat) {
+        const int reach = rt_filter_halo(iterations);
+        flat = std::max(target.x0 - reach, 0) >= c->flatRect.x0 && std::max(target.y0 - reach, 0) >= c->flatRect.y0 &&
+               std::min(target.x1 + reach, c->width) <= c->flatRect.x1 &&
+               std::min(target.y1 + reach, c->height) <= c->flatRect.y1;
+    }
+    const int cellsX = (c->width + 15) >> RT_CELL_SHIFT, cellsY = (c->height + 15) >> RT_CELL_SHIFT;
+    if (flat) {
+        float cp[RT_FLAT_MAX_PASSES], np[RT_FLAT_MAX_PASSES], pp[RT_FLAT_MAX_PASSES];
+        for (int i = 0; i < iterations; ++i) { // (the same expressions as in the loop below)
+            cp[i] = 1.0f / (float)i * c_phi0;
+            pp[i] = 1.0f / (float)(1 << i) * p_phi0;
+            np[i] = 1.0f / (float)(1 << i) * n_phi0;
+        }
+        RtFlatCells rec;
+        rec.flag = (uint8_t *)c->flatFlag.p;
+        rec.color = (float4 *)c->flatColor.p;
+        rec.normal = (uint32_t *)c->flatNormal.p;
+        rec.pos = (uint2 *)c->flatPos.p;
+        rec.cellsX = cellsX;
+        rec.cellsY = cellsY;
+        SpanGuard span(c, TK_FILTER);
+        hipError_t e = rtLaunchFlatLevels(rec, (uint8_t *)c->flatLevel.p, (uint2 *)c->flatTexels.p, c->width, c->height,
+                                          iterations, cp, np, pp, c->stream);
+        span.end();
+        if (e != hipSuccess) return hipFail(c, e, "flat levels launch");
+    }
+    c->filterUsedFlat = flat;
     for (int i = 0; i < iterations; ++i) {
         const float c_phi = 1.0f / (float)i * c_phi0; // +inf at i = 0, as the reference computes it
         const float p_phi = 1.0f / (float)(1 << i) * p_phi0;
@@ -1043,10 +1105,17 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
         r.y0 = target.y0 - grow < 0 ? 0 : target.y0 - grow;
         r.x1 = target.x1 + grow > c->width ? c->width : target.x1 + grow;
         r.y1 = target.y1 + grow > c->height ? c->height : target.y1 + grow;
+        RtFilterCells cells{};
+        if (flat) {
+            cells.level = (const uint8_t *)c->flatLevel.p;
+            cells.texel = (const uint2 *)c->flatTexels.p + (size_t)i * cellsX * cellsY;
+            cells.cellsX = cellsX;
+            cells.pass = i;
+        }
         SpanGuard span(c, TK_FILTER);
         hipError_t e = rtLaunchAtrous(readF32, readF16, (const uint32_t *)c->normal.p, (const uint2 *)c->pos.p,
                                       (uint2 *)c->filt[write].p, c->width, c->height, r, c_phi, n_phi, p_phi, step,
-                                      c->stream);
+                                      cells, c->stream);
         span.end();
         if (e != hipSuccess) return hipFail(c, e, "atrous launch");
         readF32 = nullptr;
@@ -1054,6 +1123,23 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
         c->filteredIndex = write;
         write ^= 1;
     }
+    return RT_OK;
+}
+
+int rt_flat_cells(rt_ctx *c, int which, uint8_t *flags, size_t nbytes) {
+    if (!c || !flags) return RT_EINVAL;
+    if (which != 0 && which != 1) return fail(c, RT_EINVAL, "rt_flat_cells: which must be 0 or 1");
+    const size_t need = (size_t)((c->width + 15) >> RT_CELL_SHIFT) * (size_t)((c->height + 15) >> RT_CELL_SHIFT);
+    if (nbytes != need) return fail(c, RT_EINVAL, "rt_flat_cells: size mismatch, need " + std::to_string(need));
+    const void *src = nullptr;
+    if (which == 0 && c->flatValid) src = c->flatFlag.p;
+    if (which == 1 && c->filterUsedFlat && c->filteredIndex >= 0) src = c->flatLevel.p;
+    if (!src) return fail(c, RT_ESTATE, "rt_flat_cells: no such record");
+    int rc = bind(c);
+    if (rc) return rc;
+    if ((rc = rtJoinLanes(c))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(flags, src, need, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 
@@ -1110,6 +1196,7 @@ int rt_write_image(rt_ctx *c, int image, const void *src, size_t nbytes) {
     int rc = bind(c);
     if (rc) return rc;
     if ((rc = rtJoinLanes(c))) return rc;
+    c->flatValid = false;
     HIP_TRY(c, hipMemcpyAsync(im.p, src, need, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
@@ -1131,7 +1218,10 @@ static int rectCopy(rt_ctx *c, int image, const rt_rect *tile, void *dev, size_t
     char *imgAt = (char *)im.p + ((size_t)r.y0 * c->width + r.x0) * im.pixelBytes;
     const size_t pitch = (size_t)c->width * im.pixelBytes;
     if (toCaller) HIP_TRY(c, hipMemcpy2DAsync(dev, rowBytes, imgAt, pitch, rowBytes, rows, hipMemcpyDeviceToDevice, c->stream));
-    else HIP_TRY(c, hipMemcpy2DAsync(imgAt, pitch, dev, rowBytes, rowBytes, rows, hipMemcpyDeviceToDevice, c->stream));
+    else {
+        c->flatValid = false;
+        HIP_TRY(c, hipMemcpy2DAsync(imgAt, pitch, dev, rowBytes, rowBytes, rows, hipMemcpyDeviceToDevice, c->stream));
+    }
     if (wait) HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }

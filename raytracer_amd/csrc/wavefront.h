@@ -60,6 +60,7 @@ struct WfBuffers {
     // straight to the images.
     uint32_t *stageNormal;
     uint2 *stagePos;
+    RtFlatCells flat;   // the record of flat cells the blend kernel keeps (flag null: none)
     int capacity;
     int tilePixels;
 };

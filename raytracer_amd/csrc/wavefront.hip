@@ -1001,14 +1001,23 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
 }
 
 // ------------------------------------------------------------------------------------------ blend
-// main()'s accumulation (trace3.cs:808-817), once per sample of the batch, in sample order.
-__global__ __launch_bounds__(256) void rt_wf_blend_kernel(RtImages img, WfParams p, WfBuffers wf, rt_rect tile) {
+// main()'s accumulation (trace3.cs:808-817), once per sample of the batch, in sample order.  The frame's last
+// kernel: it commits the colour (and the staged G-buffer, when there is one) to the caller-visible images.  One
+// block per 16 x 16 cell of the image that the tile touches, so that the block can also record whether it left the
+// cell flat (RtFlatCells, rt_device.h): a cell the tile covers only in part is never recorded as flat.
+__global__ __launch_bounds__(256) void rt_wf_blend_kernel(RtImages img, WfParams p, WfBuffers wf, rt_rect tile,
+                                                          int cellX0, int cellY0, int cellsAcross) {
+    const int cx = cellX0 + (int)blockIdx.x % cellsAcross, cy = cellY0 + (int)blockIdx.x / cellsAcross;
+    const int x = (cx << RT_CELL_SHIFT) + (threadIdx.x & 15), y = (cy << RT_CELL_SHIFT) + (threadIdx.x >> 4);
+    const bool inTile = x >= tile.x0 && x < tile.x1 && y >= tile.y0 && y < tile.y1;
     const int tw = tile.x1 - tile.x0;
     const int n = wf.tilePixels;
-    for (int tp = blockIdx.x * 256 + threadIdx.x; tp < n; tp += gridDim.x * 256) {
-        const int x = tile.x0 + tp % tw, y = tile.y0 + tp / tw;
+    float4 cur = make_float4(0, 0, 0, 0);
+    uint32_t nrm = 0;
+    uint2 ps = make_uint2(0, 0);
+    if (inTile) {
+        const int tp = (y - tile.y0) * tw + (x - tile.x0);
         const size_t pix = (size_t)y * img.width + x;
-        float4 cur = make_float4(0, 0, 0, 0);
         bool loaded = false;
         const float4 L0 = wf.radiance[tp];
         const bool allSame = L0.w < 0.0f; // a pixel whose primary ray missed the scene box: one value for the batch
@@ -1025,8 +1034,39 @@ __global__ __launch_bounds__(256) void rt_wf_blend_kernel(RtImages img, WfParams
         }
         img.color[pix] = cur;
         if (wf.stageNormal) { // the frame's G-buffer becomes visible with its colour
-            img.normal[pix] = wf.stageNormal[pix];
-            img.pos[pix] = wf.stagePos[pix];
+            nrm = wf.stageNormal[pix];
+            ps = wf.stagePos[pix];
+            img.normal[pix] = nrm;
+            img.pos[pix] = ps;
+        } else if (wf.flat.flag) { // (written earlier in this launch by the classify / logic kernels)
+            nrm = img.normal[pix];
+            ps = img.pos[pix];
+        }
+    }
+    if (!wf.flat.flag) return;
+    __shared__ float4 firstColor;
+    __shared__ uint32_t firstNormal;
+    __shared__ uint2 firstPos;
+    if (threadIdx.x == 0) { // (the cell's first pixel is inside the image: the cell touches the tile)
+        firstColor = cur;
+        firstNormal = nrm;
+        firstPos = ps;
+    }
+    __syncthreads();
+    const bool inImage = x < img.width && y < img.height;
+    const bool same = !inImage || (inTile && __float_as_uint(cur.x) == __float_as_uint(firstColor.x) &&
+                                   __float_as_uint(cur.y) == __float_as_uint(firstColor.y) &&
+                                   __float_as_uint(cur.z) == __float_as_uint(firstColor.z) &&
+                                   __float_as_uint(cur.w) == __float_as_uint(firstColor.w) && nrm == firstNormal &&
+                                   ps.x == firstPos.x && ps.y == firstPos.y);
+    const int flat = __syncthreads_and(same ? 1 : 0);
+    if (threadIdx.x == 0) {
+        const int cell = cy * wf.flat.cellsX + cx;
+        wf.flat.flag[cell] = flat ? 1 : 0;
+        if (flat) {
+            wf.flat.color[cell] = cur;
+            wf.flat.normal[cell] = nrm;
+            wf.flat.pos[cell] = ps;
         }
     }
 }
@@ -1097,14 +1137,16 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
         if (prof) rtMarkKernel(prof, RT_TIME_WF_LOGIC, false);
         if (b < p.maxBounces) extend(b + 1);
     }
-    int blendBlocks = (tw * th + 255) / 256;
-    if (blendBlocks > 4096) blendBlocks = 4096;
+    const int cellX0 = tile.x0 >> RT_CELL_SHIFT, cellY0 = tile.y0 >> RT_CELL_SHIFT;
+    const int cellsAcross = ((tile.x1 - 1) >> RT_CELL_SHIFT) - cellX0 + 1;
+    const int blendBlocks = cellsAcross * (((tile.y1 - 1) >> RT_CELL_SHIFT) - cellY0 + 1);
     if (beforeCommit) {
         hipError_t w = hipStreamWaitEvent(stream, beforeCommit, 0);
         if (w != hipSuccess) return w;
     }
     if (prof) rtMarkKernel(prof, RT_TIME_WF_BLEND, true);
-    hipLaunchKernelGGL(rt_wf_blend_kernel, dim3(blendBlocks), dim3(256), 0, stream, imgOut, p, wf, tile);
+    hipLaunchKernelGGL(rt_wf_blend_kernel, dim3(blendBlocks), dim3(256), 0, stream, imgOut, p, wf, tile,
+                       cellX0, cellY0, cellsAcross);
     if (prof) rtMarkKernel(prof, RT_TIME_WF_BLEND, false);
     return hipGetLastError();
 }

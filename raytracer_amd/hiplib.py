@@ -70,7 +70,7 @@ EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_uplo
            "rt_clear", "rt_trace", "rt_trace_batch", "rt_trace_batch_static", "rt_static_max_paths", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
            "rt_readback_rect_device", "rt_write_rect_device", "rt_write_rect_device_async", "rt_write_image", "rt_image_pixel_bytes",
            "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
-           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_gather_tiles", "rt_walk_stop", "rt_set_frames_in_flight", "rt_frames_in_flight",
+           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_gather_tiles", "rt_walk_stop", "rt_set_frames_in_flight", "rt_frames_in_flight", "rt_flat_cells",
            "rt_work_group_size", "rt_version"]
 
 _lib = None
@@ -122,6 +122,7 @@ def lib():
         L.rt_walk_stop.argtypes = [vp]
         L.rt_set_frames_in_flight.argtypes = [vp, i32]
         L.rt_frames_in_flight.argtypes = [vp]
+        L.rt_flat_cells.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t]
         L.rt_work_group_size.argtypes = [i32, ctypes.POINTER(ctypes.c_int * 3)]
         L.rt_work_group_size.restype = None
         L.rt_version.restype = ctypes.c_char_p
@@ -309,6 +310,17 @@ class Context:
     def set_frames_in_flight(self, n):
         """n > 1 (default 3): successive frames rotate over n internal streams; 1: one frame at a time."""
         self._check(lib().rt_set_frames_in_flight(self._h, int(n)), "rt_set_frames_in_flight")
+
+    def flat_cells(self, which=0):
+        """rt_flat_cells: the flags of the 16 x 16 cells recorded as flat, [cellsY, cellsX] (0: by the last wavefront
+        frame, 1: by the last rt_filter); None when there is no such record."""
+        cx, cy = (self.width + 15) // 16, (self.height + 15) // 16
+        out = np.zeros((cy, cx), np.uint8)
+        r = lib().rt_flat_cells(self._h, which, out.ctypes.data_as(ctypes.c_void_p), out.nbytes)
+        if r == -4:  # RT_ESTATE
+            return None
+        self._check(r, "rt_flat_cells")
+        return out
 
     def readback(self, image):
         dt, ch = _IMAGE_DTYPES[image]

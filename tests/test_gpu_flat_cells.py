@@ -1,0 +1,138 @@
+"""Flat cells (include/rt_launcher.h: rt_flat_cells; raytracer_amd/csrc/rt_device.h: RtFlatCells).  The record is an
+optimisation of rt_filter for frames with a flat background: every image must be bit for bit what it is without the
+record (RT_FILTER_CELLS=0), the record itself must say exactly which 16 x 16 cells the frame left with one texel, and
+it must be dropped whenever something else writes the images."""
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import hiplib, workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def make_ctx(wl, W, H, cells_on):
+    old = os.environ.get("RT_FILTER_CELLS")
+    os.environ["RT_FILTER_CELLS"] = "1" if cells_on else "0"
+    try:
+        ctx = hiplib.Context(0)
+    finally:
+        if old is None:
+            del os.environ["RT_FILTER_CELLS"]
+        else:
+            os.environ["RT_FILTER_CELLS"] = old
+    ctx.upload_scene(wl.buffers)
+    ctx.resize(W, H)
+    return ctx
+
+
+def cells_of(img, W, H):
+    """[cellsY, cellsX] True where every texel of the 16 x 16 cell (its part inside the image) has the same bytes."""
+    raw = np.ascontiguousarray(img).view(np.uint8).reshape(H, W, -1)
+    cy, cx = (H + 15) // 16, (W + 15) // 16
+    out = np.zeros((cy, cx), bool)
+    for j in range(cy):
+        for i in range(cx):
+            blk = raw[16 * j:16 * j + 16, 16 * i:16 * i + 16]
+            out[j, i] = bool((blk == blk[0, 0]).all())
+    return out
+
+
+def same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+
+
+@pytest.mark.parametrize("W,H,iters", [(960, 540, 5), (333, 215, 5), (203, 131, 3)])
+def test_filter_with_the_record_equals_filter_without(W, H, iters):
+    wl = workloads.Workload("scene", W, H)
+    on, off = make_ctx(wl, W, H, True), make_ctx(wl, W, H, False)
+    try:
+        for k in range(3):  # accumulating frames: the blend mixes with the history, flat cells stay flat
+            for ctx in (on, off):
+                ctx.trace_samples(wl.rays, wl.eye, spp=2, frame0=2 * k, max_bounces=3, num_emitters=wl.num_emitters)
+                ctx.filter(iters)
+            assert off.flat_cells(0) is None and off.flat_cells(1) is None
+            for image in (hiplib.IMAGE_COLOR, hiplib.IMAGE_NORMAL, hiplib.IMAGE_POSITION, hiplib.IMAGE_FILTERED):
+                assert same_bits(on.readback(image), off.readback(image)), (k, image)
+            # the frame's record: exactly the cells whose colour, normal and position texels are all equal
+            flags = on.flat_cells(0)
+            want = (cells_of(on.readback(hiplib.IMAGE_COLOR), W, H) & cells_of(on.readback(hiplib.IMAGE_NORMAL), W, H)
+                    & cells_of(on.readback(hiplib.IMAGE_POSITION), W, H))
+            assert np.array_equal(flags.astype(bool), want)
+            assert 0.2 < flags.mean() < 0.99  # the scene has both sky and geometry
+            # the filter's levels: a cell with a per-cell result of the last pass is flat in the filtered image, and away
+            # from the geometry and the image edge there are such cells (each pass reaches further: small images have none)
+            levels = on.flat_cells(1)
+            assert levels is not None and levels.max() <= iters and not (levels.astype(bool) & ~flags.astype(bool)).any()
+            done = levels == iters
+            assert done.sum() > 0 or W < 900
+            flat_out = cells_of(on.readback(hiplib.IMAGE_FILTERED), W, H)
+            assert not (done & ~flat_out).any()
+    finally:
+        on.close()
+        off.close()
+
+
+def test_tiles_with_halo_and_the_record():
+    """The multi-GPU pattern: trace the tile grown by the filter's halo, filter the tile.  With and without the record."""
+    W, H, iters = 320, 200, 4
+    wl = workloads.Workload("scene", W, H)
+    on, off = make_ctx(wl, W, H, True), make_ctx(wl, W, H, False)
+    try:
+        halo = hiplib.lib().rt_filter_halo(iters)
+        tile = (0, 37, W, 141)
+        grown = (0, max(tile[1] - halo, 0), W, min(tile[3] + halo, H))
+        for ctx in (on, off):
+            ctx.trace_samples(wl.rays, wl.eye, spp=2, max_bounces=3, num_emitters=wl.num_emitters, rect=grown)
+            ctx.filter(iters, rect=tile)
+        assert on.flat_cells(1) is not None  # (the grown tile covers everything the first pass reads)
+        a, b = on.readback(hiplib.IMAGE_FILTERED), off.readback(hiplib.IMAGE_FILTERED)
+        assert same_bits(a[tile[1]:tile[3]], b[tile[1]:tile[3]])
+        # a filter that reads beyond the traced tile cannot use the record
+        on.filter(iters)
+        off.filter(iters)
+        assert on.flat_cells(1) is None
+        assert same_bits(on.readback(hiplib.IMAGE_FILTERED), off.readback(hiplib.IMAGE_FILTERED))
+    finally:
+        on.close()
+        off.close()
+
+
+def test_the_record_is_dropped_when_something_else_writes_the_images():
+    W, H, iters = 256, 160, 4
+    wl = workloads.Workload("scene", W, H)
+    on, off = make_ctx(wl, W, H, True), make_ctx(wl, W, H, False)
+    try:
+        def frame(ctx):
+            ctx.trace_samples(wl.rays, wl.eye, spp=1, max_bounces=2, num_emitters=wl.num_emitters)
+
+        frame(on)
+        frame(off)
+        assert on.flat_cells(0) is not None
+        # the caller replaces the colour image (noise where the sky was): the filter must see the new texels
+        rng = np.random.default_rng(5)
+        noise = rng.random((H, W, 4), dtype=np.float32)
+        for ctx in (on, off):
+            ctx.write_image(hiplib.IMAGE_COLOR, noise)
+            ctx.filter(iters)
+        assert on.flat_cells(0) is None and on.flat_cells(1) is None
+        assert same_bits(on.readback(hiplib.IMAGE_FILTERED), off.readback(hiplib.IMAGE_FILTERED))
+        # the per-pixel kernel writes the images without keeping a record
+        frame(on)
+        assert on.flat_cells(0) is not None
+        for ctx in (on, off):
+            ctx.trace_samples(wl.rays, wl.eye, spp=1, max_bounces=2, num_emitters=wl.num_emitters,
+                              flags=hiplib.FLAG_PER_PIXEL_KERNEL)
+            ctx.filter(iters)
+        assert on.flat_cells(0) is None
+        assert same_bits(on.readback(hiplib.IMAGE_FILTERED), off.readback(hiplib.IMAGE_FILTERED))
+        # clear drops it too; the next wavefront frame makes a new one
+        frame(on)
+        on.clear()
+        assert on.flat_cells(0) is None
+        frame(on)
+        assert on.flat_cells(0) is not None
+    finally:
+        on.close()
+        off.close()
