@@ -148,17 +148,44 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
     const int x0 = rect.x0 + tileCol * TX, y0 = rect.y0 + tileRow * TY;
     const PassScalars ks = passScalars(c_phi, n_phi, p_phi, step);
     // Flat cells (rt_device.h): a tile all of whose cells have this pass's result per cell stores those and is done.
+    // A 256 x 1 tile spans 16 or 17 cells, so there it is decided cell by cell: only the texels that pixels of the
+    // other cells read are staged, and only those pixels are filtered.
+    unsigned flatCells = 0;          // BANDS: bit i = the tile's i-th cell has a per-cell result
+    unsigned needCols = 0xFFFFFFFFu; // BANDS: bit j = texels of cell column cxa - 4 + j are staged
+    const int cxa = x0 >> RT_CELL_SHIFT;
+    uint2 cellTexel = make_uint2(0, 0); // the per-cell result of this thread's pixel, if its cell has one
     if (cells.level) {
+        // (read together with the levels, before they are known: one trip to memory for a tile that is done with it)
+        const int px = x0 + (int)threadIdx.x % TX, py = y0 + (int)threadIdx.x / TX;
+        if (px < rect.x1 && py < rect.y1) cellTexel = cells.texel[(py >> RT_CELL_SHIFT) * cells.cellsX + (px >> RT_CELL_SHIFT)];
         const int xe = min(x0 + TX, rect.x1), ye = min(y0 + TY, rect.y1);
-        const int cxa = x0 >> RT_CELL_SHIFT, cya = y0 >> RT_CELL_SHIFT;
+        const int cya = y0 >> RT_CELL_SHIFT;
         const int ncx = ((xe - 1) >> RT_CELL_SHIFT) - cxa + 1, ncy = ((ye - 1) >> RT_CELL_SHIFT) - cya + 1;
+        const bool counts = (int)threadIdx.x < ncx * ncy;
         int mine = 1;
-        if ((int)threadIdx.x < ncx * ncy)
+        if (counts)
             mine = cells.level[(cya + (int)threadIdx.x / ncx) * cells.cellsX + cxa + (int)threadIdx.x % ncx] > cells.pass;
-        if (__syncthreads_and(mine)) {
+        bool allFlat;
+        if constexpr (BANDS) {
+            static_assert(!BANDS || TY == 1, "one row of cells per tile");
+            __shared__ unsigned sFlatCells;
+            const unsigned long long votes = __ballot(counts && mine); // (the tile's cells: threads 0 .. 16, all in wave 0)
+            if (threadIdx.x == 0) sFlatCells = (unsigned)votes;
+            __syncthreads();
+            flatCells = sFlatCells;
+            const unsigned every = (1u << ncx) - 1u;
+            allFlat = flatCells == every;
+            // a pixel reads texels up to `step` pixels to either side: the cell columns within ceil(step / 16) of its own
+            const unsigned others = (every & ~flatCells) << 4;
+            const int R = (step + 15) >> RT_CELL_SHIFT;
+            needCols = others;
+            for (int d = 1; d <= R; ++d) needCols |= (others << d) | (others >> d);
+        } else {
+            allFlat = __syncthreads_and(mine) != 0;
+        }
+        if (allFlat) {
             const int x = x0 + (int)threadIdx.x % TX, y = y0 + (int)threadIdx.x / TX;
-            if (x < rect.x1 && y < rect.y1)
-                out[(size_t)y * W + x] = cells.texel[(y >> RT_CELL_SHIFT) * cells.cellsX + (x >> RT_CELL_SHIFT)];
+            if (x < rect.x1 && y < rect.y1) out[(size_t)y * W + x] = cellTexel;
             return;
         }
     }
@@ -170,7 +197,7 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
     float4 cv[kMaxTexels];
     uint2 cvh[kMaxTexels], pvh[kMaxTexels];
     uint32_t nvr[kMaxTexels];
-    bool inside[kMaxTexels];
+    bool inside[kMaxTexels], staged[kMaxTexels];
 #pragma unroll
     for (int k = 0; k < kMaxTexels; ++k) {
         const int e = threadIdx.x + 256 * k;
@@ -178,7 +205,8 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
         // BANDS: staged row (o+1)*TY + r holds image row y0 + r + o*step; else staged row r holds y0 - step + r
         const int sy = BANDS ? y0 + (row % TY) + (row / TY - 1) * step : y0 - step + row;
         const int sx = x0 - step + c;
-        inside[k] = e < rows * cols && sx >= 0 && sy >= 0 && sx < W && sy < H;
+        staged[k] = e < rows * cols && (!BANDS || ((needCols >> (((sx >> RT_CELL_SHIFT) - cxa + 4) & 31)) & 1u));
+        inside[k] = staged[k] && sx >= 0 && sy >= 0 && sx < W && sy < H;
         cv[k] = make_float4(0, 0, 0, 0);
         cvh[k] = pvh[k] = make_uint2(0, 0);
         nvr[k] = 0;
@@ -193,7 +221,7 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
 #pragma unroll
     for (int k = 0; k < kMaxTexels; ++k) {
         const int e = threadIdx.x + 256 * k;
-        if (e < rows * cols) {
+        if (staged[k]) {
             float4 c, nv, pv;
             unpackTexel(colorF32 != nullptr, cv[k], cvh[k], nvr[k], pvh[k], c, nv, pv);
             sCol[e] = c;
@@ -206,6 +234,10 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
     const int lx = threadIdx.x % TX, ly = threadIdx.x / TX;
     const int x = x0 + lx, y = y0 + ly;
     if (x >= rect.x1 || y >= rect.y1) return;
+    if (BANDS && ((flatCells >> ((x >> RT_CELL_SHIFT) - cxa)) & 1u)) {
+        out[(size_t)y * W + x] = cellTexel;
+        return;
+    }
 
     const int rowStride = BANDS ? TY * cols : step * cols; // from a tap row to the next
     const int centre = (BANDS ? TY + ly : ly + step) * cols + step + lx;
