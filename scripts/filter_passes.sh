@@ -15,4 +15,13 @@ for r in csv.DictReader(open(sys.argv[1])):
     if "atrous" in n or "flat" in n or "blend" in n:
         print(n[:70], r["Calls"], "avg_us", round(float(r["AverageNs"]) / 1e3, 2), "min_us", round(float(r["MinNs"]) / 1e3, 2))
 PY
+  t=$(find /tmp/fp_$mode -name "*kernel_trace.csv" | head -1)
+  python3 - "$t" >> $REPO/gpurun_out/filter_passes_$mode.txt <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "atrous" in r["Kernel_Name"] or "flat_levels" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+print("last frame, in order:")
+for r in rows[-6:]:
+    print("  ", r["Kernel_Name"][:48], "grid", r.get("Grid_Size_X", r.get("Grid_Size", "?")), "lds", r.get("LDS_Block_Size", "?"), "us", round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 2))
+PY
 done
