@@ -525,32 +525,75 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         // launcher times both, rt_launcher.hip).  Beyond the L2s every step is a trip to memory and stopping early
         // pays at any width (walkMin = 1).
         if (walkStop < 8 && walking >= p.walkMin) stopAt = max(1, (walking * walkStop) >> 3);
-        while (active && next != -1 && leafCount == 0 && found < stopAt) {
-            iterations++;
-            if (iterations > p.maxFollows) { // trace3.cs:228-234
+        if constexpr (NODES == NODES_ANY) {
+            while (active && next != -1 && leafCount == 0 && found < stopAt) {
+                iterations++;
+                if (iterations > p.maxFollows) { // trace3.cs:228-234
+                    hitTri = -1;
+                    next = -1;
+                    bounded = false; // an aborted walk proves nothing: reported as a miss, i.e. not visible
+                    break;
+                }
+                float4 b0, b1;
+                NodeLinks k;
+                loadNodeT<NODES>(sc, next, b0, b1, k);
+                const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
+                            m1z = (b0.z - origin.z) * invdir.z;
+                const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
+                            m2z = (b1.z - origin.z) * invdir.z;
+                const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
+                const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
+                const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f; // geometry.glsl:66-76
+                if (!boxHit || mint > nearest) {
+                    next = k.missNext;
+                } else {
+                    leafFirst = k.leafFirst;
+                    leafCount = k.leafCount;
+                    next = k.hitNext;
+                }
+                if (walkStop < 8) found += __popcll(__ballot(leafCount > 0));
+            }
+        } else {
+            // Packed records (trace3_device.h: loadNodeT), the loop written for instruction count — the kernel is bound
+            // by VALU issue on dense frames and by the length of this dependent chain on sparse ones.  The leaf a lane
+            // enters is kept as the record's raw word and decoded after the loop; the MAX_FOLLOWS abort (trace3.cs:
+            // 228-234: the visit after the maxFollows-th) is taken after the loop by the lanes the limit stopped.
+            int leafWord = 0; // w1 of the leaf entered (negative), 0: none yet
+            // (vmcnt(0) lgkmcnt(0): nothing is in flight here in practice, but the compiler cannot prove it for the registers
+            // the loop reuses and would otherwise wait between the loop's two LDS reads, on every step)
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            while (active && next != -1 && leafWord == 0 && iterations < p.maxFollows && found < stopAt) {
+                iterations++;
+                float4 b0, b1;
+                if (NODES == NODES_PACKED_LDS || next < sc.cacheNodes) {
+                    b0 = rtLdsNodes[2 * next];
+                    b1 = rtLdsNodes[2 * next + 1];
+                } else {
+                    b0 = sc.boxes[2 * next];
+                    b1 = sc.boxes[2 * next + 1];
+                }
+                const int w0 = __float_as_int(b0.w), w1 = __float_as_int(b1.w);
+                const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
+                            m1z = (b0.z - origin.z) * invdir.z;
+                const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
+                            m2z = (b1.z - origin.z) * invdir.z;
+                const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
+                const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
+                const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f; // geometry.glsl:66-76
+                const bool enter = boxHit && !(mint > nearest);
+                const bool leaf = w1 < 0;
+                next = (enter && !leaf) ? w1 : w0; // (a leaf's hitNext equals its missNext)
+                leafWord = (enter && leaf) ? w1 : 0;
+                if (walkStop < 8) found += __popcll(__builtin_amdgcn_ballot_w64(enter && leaf));
+            }
+            if (active && next != -1 && leafWord == 0 && iterations >= p.maxFollows) {
+                iterations++; // the visit that the reference's loop starts and abandons
                 hitTri = -1;
                 next = -1;
                 bounded = false; // an aborted walk proves nothing: reported as a miss, i.e. not visible
-                break;
             }
-            float4 b0, b1;
-            NodeLinks k;
-            loadNodeT<NODES>(sc, next, b0, b1, k);
-            const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
-                        m1z = (b0.z - origin.z) * invdir.z;
-            const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
-                        m2z = (b1.z - origin.z) * invdir.z;
-            const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
-            const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
-            const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f; // geometry.glsl:66-76
-            if (!boxHit || mint > nearest) {
-                next = k.missNext;
-            } else {
-                leafFirst = k.leafFirst;
-                leafCount = k.leafCount;
-                next = k.hitNext;
-            }
-            if (walkStop < 8) found += __popcll(__ballot(leafCount > 0));
+            leafFirst = leafWord & 0x03FFFFFF;
+            leafCount = leafWord != 0 ? ((leafWord >> 26) & 31) + 1 : 0;
         }
         WT({
             int d = active ? iterations - wtIt0 : 0;
