@@ -193,6 +193,10 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
     // Staging in two sweeps: first every global load of this thread's texels is issued (one trip to memory for all of
     // them: large steps leave room for few blocks per CU, so the latency is not hidden by other blocks), then they
     // are unpacked and written to LDS.
+    // e / cols for e < 2048 and cols < 512 by one multiplication (exact there: the error of the rounded-up reciprocal,
+    // e / 2^20 < 1 / 512, is below the smallest distance 1 / cols of e / cols from the next integer); the division by
+    // a run-time divisor was a fifth of the kernel's instructions
+    const unsigned colsMagic = ((1u << 20) + (unsigned)cols - 1u) / (unsigned)cols;
     constexpr int kMaxTexels = BANDS ? (3 * TY * (TX + 2 * FT_MAXSTEP) + 255) / 256 : ((TY + 8) * (TX + 8) + 255) / 256;
     float4 cv[kMaxTexels];
     uint2 cvh[kMaxTexels], pvh[kMaxTexels];
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
 #pragma unroll
     for (int k = 0; k < kMaxTexels; ++k) {
         const int e = threadIdx.x + 256 * k;
-        const int row = e / cols, c = e - row * cols;
+        const int row = (int)(((unsigned)e * colsMagic) >> 20), c = e - row * cols;
         // BANDS: staged row (o+1)*TY + r holds image row y0 + r + o*step; else staged row r holds y0 - step + r
         const int sy = BANDS ? y0 + (row % TY) + (row / TY - 1) * step : y0 - step + row;
         const int sx = x0 - step + c;
