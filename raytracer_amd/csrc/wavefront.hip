@@ -640,48 +640,57 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 const unsigned long long atOrBelow = (2ull << lane) - 1ull;
                 int rankBase = -1; // rank of the last ray that starts before this round
                 unsigned long long heads = ws->heads[0];
-                int g = lane, o = 0, tri = 0;
-                float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0;
-                // (RT_FLAG_WATERTIGHT: a0..a2 are the three vertices from the 128-byte records instead of {v0, e1, e2})
+                // (RT_FLAG_WATERTIGHT: v0..v2 are the three vertices from the 128-byte records instead of {v0, e1, e2})
                 const float4 *triData = WATERTIGHT ? reinterpret_cast<const float4 *>(sc.tris128) : sc.tris48;
                 constexpr int triStride = WATERTIGHT ? 8 : 3;
-                if (g < totalTests) {
-                    o = rankBase + __popcll(heads & atOrBelow);
-                    tri = ws->first[o] + g;
-                    a0 = triData[triStride * tri];
-                    a1 = triData[triStride * tri + 1];
-                    a2 = triData[triStride * tri + 2];
+                struct Pair { // pair g of the list: ray of rank o, triangle tri
+                    int g, o, tri;
+                    float4 v0, v1, v2;
+                };
+                Pair pa, pb; // the pair of this round and the pair of the next, by turns (no copying between rounds)
+                pa.g = lane, pa.o = 0, pa.tri = 0;
+                pa.v0 = pa.v1 = pa.v2 = make_float4(0, 0, 0, 0);
+                pb = pa;
+                if (pa.g < totalTests) {
+                    pa.o = rankBase + __popcll(heads & atOrBelow);
+                    pa.tri = ws->first[pa.o] + pa.g;
+                    pa.v0 = triData[triStride * pa.tri];
+                    pa.v1 = triData[triStride * pa.tri + 1];
+                    pa.v2 = triData[triStride * pa.tri + 2];
                 }
-                for (int base = 0; base < totalTests; base += 64) {
-                    const int gn = g + 64;
-                    int on = 0, trin = 0;
-                    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+                // one round: request the triangle of the next round's pair, then test this round's
+                auto round = [&](const Pair &cur, Pair &nxt, int base) {
+                    nxt.g = cur.g + 64;
                     rankBase += __popcll(heads);
                     if (base + 64 < totalTests) heads = ws->heads[(base >> 6) + 1];
-                    if (gn < totalTests) {
-                        on = rankBase + __popcll(heads & atOrBelow);
-                        trin = ws->first[on] + gn;
-                        n0 = triData[triStride * trin];
-                        n1 = triData[triStride * trin + 1];
-                        n2 = triData[triStride * trin + 2];
+                    if (nxt.g < totalTests) {
+                        nxt.o = rankBase + __popcll(heads & atOrBelow);
+                        nxt.tri = ws->first[nxt.o] + nxt.g;
+                        nxt.v0 = triData[triStride * nxt.tri];
+                        nxt.v1 = triData[triStride * nxt.tri + 1];
+                        nxt.v2 = triData[triStride * nxt.tri + 2];
                     }
-                    if (g < totalTests) {
-                        const float4 ro = ws->ro[o], rd = ws->rd[o];
+                    if (cur.g < totalTests) {
+                        const float4 ro = ws->ro[cur.o], rd = ws->rd[cur.o];
                         float tn = ro.w, tt = 0.0f, tu = 0.0f, tv = 0.0f;
                         int th = -1;
                         if (WATERTIGHT)
-                            testTriangleWt(xyz(a0), xyz(a1), xyz(a2), tri, F3(ro.x, ro.y, ro.z), wtSetup(F3(rd.x, rd.y, rd.z)), tn,
-                                           th, tt, tu, tv);
+                            testTriangleWt(xyz(cur.v0), xyz(cur.v1), xyz(cur.v2), cur.tri, F3(ro.x, ro.y, ro.z),
+                                           wtSetup(F3(rd.x, rd.y, rd.z)), tn, th, tt, tu, tv);
                         else
-                            testTriangle<false>(a0, a1, a2, tri, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), tn, th, tt, tu, tv);
+                            testTriangle<false>(cur.v0, cur.v1, cur.v2, cur.tri, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), tn,
+                                                th, tt, tu, tv);
                         if (th >= 0) { // t >= 0 and t < the ray's nearest; -0.0 is keyed as +0.0
                             const unsigned long long key =
-                                ((unsigned long long)__float_as_uint(tt + 0.0f) << 32) | (unsigned)tri;
-                            atomicMin(&ws->key[o], key);
+                                ((unsigned long long)__float_as_uint(tt + 0.0f) << 32) | (unsigned)cur.tri;
+                            atomicMin(&ws->key[cur.o], key);
                         }
                     }
-                    g = gn; o = on; tri = trin;
-                    a0 = n0; a1 = n1; a2 = n2;
+                };
+                for (int base = 0; base < totalTests; base += 128) {
+                    round(pa, pb, base);
+                    if (base + 64 >= totalTests) break;
+                    round(pb, pa, base + 64);
                 }
                 if (lane * 64 < totalTests) ws->heads[lane] = 0ull; // leave the bit string clear for the next round
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
