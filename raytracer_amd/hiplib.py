@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librt_hip.so")
+LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "lib", "librt_hip.so")  # RT_HIP_LIB: another build of it
 
 (IMAGE_COLOR, IMAGE_NORMAL, IMAGE_POSITION, IMAGE_FILTERED, IMAGE_TRIDX, IMAGE_VISITS, IMAGE_STATS,
  IMAGE_LDR, IMAGE_ASSEMBLED) = range(9)
