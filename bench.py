@@ -95,7 +95,7 @@ def alone_roofline(K, ctx, step, steps, wl, W, H, spp, filter_iters, scene_key, 
         ctx.profile(False)
         r = roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, root_misses)
     finally:
-        ctx.set_frames_in_flight(before)
+        ctx.set_frames_in_flight(before if os.environ.get("RT_PIPELINE") else 0)  # 0: back to the launcher's choice
     if not r:
         return None
     return {"frames_in_flight_of_timed_region": before, **{k: r[k] for k in ("kernel", "achieved", "unit", "frac", "avg_launch_ms", "launches")}}

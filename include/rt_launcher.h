@@ -270,14 +270,15 @@ int rt_gather_tiles(rt_ctx *ctx, int image, const rt_rect *rects, int nrects, in
  * its two candidates; else the walkStop in use (eighths of the walking lanes; 8 = every lane walks to its leaf). */
 int rt_walk_stop(const rt_ctx *ctx);
 
-/* Frames in flight (no counterpart in the reference, whose GL queue is one stream): with n > 1 (default 3), successive
+/* Frames in flight (no counterpart in the reference, whose GL queue is one stream): with n > 1 (default 4), successive
  * rt_trace_batch calls of RT_KERNEL_TRACE3 rotate over n internal streams ("lanes"), each with its own pipeline memory:
  * frame k+1 is traced while frame k is still being traced / filtered, and only its last kernel, which writes colour,
  * normals and positions, waits for everything queued before the call.  The images a caller reads are the same as with
  * n = 1; what changes is the latency hidden (sparse frames leave most of the GPU idle in the tail of every stage) and
  * the memory held (412 B per pixel-sample and lane; lanes are not used when they would need more than 48 GB together).
  * Not used with RT_FLAG_AUX / RT_FLAG_PIXEL_STATS, on a caller-supplied stream, or while the launcher times its
- * schedule candidates.  n = 1 .. 4 (else RT_EINVAL); RT_PIPELINE=n sets it at rt_create (0 or 1: one frame at a time).
+ * schedule candidates.  n = 1 .. 4, or 0 for the launcher's own choice (4; 3 for scenes beyond the L2 caches, which are
+ * bound by HBM and lose with a fourth frame); else RT_EINVAL.  RT_PIPELINE=n sets it at rt_create (0 or 1: one frame at a time).
  * rt_frames_in_flight returns the current setting. */
 int rt_set_frames_in_flight(rt_ctx *ctx, int n);
 int rt_frames_in_flight(const rt_ctx *ctx);

@@ -19,7 +19,7 @@ struct DevBuf {
 enum TimeKind { TK_TRACE = RT_TIME_TRACE, TK_FILTER = RT_TIME_FILTER, TK_TONEMAP = RT_TIME_TONEMAP };
 
 #define RT_MAX_LANES 4
-#define RT_DEFAULT_LANES 3 // (+ the gather's stream = the 4 hardware queues a process gets by default)
+#define RT_DEFAULT_LANES 4 // measured 1 / 2 / 3 / 4 / 5 / 6: 1.65 / 1.09 / 0.95 / 0.90 / 1.04 / 1.04 ms per metric frame (a process has 4 hardware queues)
 
 struct TimedSpan {
     hipEvent_t start, stop;
@@ -71,6 +71,7 @@ struct rt_ctx {
     int laneNow = 0;                    // lane of the stream that `stream` currently is (when it is one of ours)
     int lanesAvailable = 1;             // lanes whose stream and event could be created
     int framesInFlight = RT_DEFAULT_LANES; // lanes in use, 1 .. RT_MAX_LANES (rt_set_frames_in_flight, RT_PIPELINE)
+    bool lanesByCaller = false;         // set by rt_set_frames_in_flight / RT_PIPELINE: then used as given; else scenes beyond the L2s get 3
     int tuneRefillLanes = 0, tuneExtendBlocks = 4;  // development knobs: RT_WF_REFILL (0: by scene size), RT_WF_BLOCKS
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
     int tuneWalkStop = 0, tuneWalkMin = 0;           // RT_WF_WALK_STOP (eighths), RT_WF_WALK_MIN: 0 = by scene size (WfParams::walkStop)

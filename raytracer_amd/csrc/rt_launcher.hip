@@ -211,15 +211,26 @@ size_t rt_image_pixel_bytes(int image) {
     }
 }
 
-int rt_frames_in_flight(const rt_ctx *c) { return c ? std::min(c->framesInFlight, c->lanesAvailable) : 0; }
+// lanes the next wavefront frame of the uploaded scene would rotate over
+static int lanesInUse(const rt_ctx *c) {
+    int lanes = std::min(c->framesInFlight, c->lanesAvailable);
+    // (a scene beyond the L2s is bound by HBM: a fourth frame in flight only adds to the cache misses — config #5
+    // 20.5 ms per frame with three, 21.3 ms with four — unless the caller asked for it)
+    const size_t hot = c->boxes.bytes + c->leaves.bytes + c->tris48.bytes;
+    if (!c->lanesByCaller && hot > (size_t)3 * 1024 * 1024) lanes = std::min(lanes, 3);
+    return lanes;
+}
+
+int rt_frames_in_flight(const rt_ctx *c) { return c ? lanesInUse(c) : 0; }
 
 int rt_set_frames_in_flight(rt_ctx *c, int n) {
     if (!c) return RT_EINVAL;
-    if (n < 1 || n > RT_MAX_LANES) return fail(c, RT_EINVAL, "rt_set_frames_in_flight: 1 .. 4");
+    if (n < 0 || n > RT_MAX_LANES) return fail(c, RT_EINVAL, "rt_set_frames_in_flight: 1 .. 4, or 0 for the launcher's choice");
     int rc = bind(c);
     if (rc) return rc;
     if ((rc = rtJoinLanes(c))) return rc;
-    n = std::min(n, c->lanesAvailable);
+    c->lanesByCaller = n != 0;
+    n = std::min(n ? n : RT_DEFAULT_LANES, c->lanesAvailable);
     c->framesInFlight = n;
     if (c->stream != c->ownStream && c->laneNow >= n) { // back to a lane that stays in use
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -259,6 +270,7 @@ int rt_create(int device_id, rt_ctx **out) {
     if (const char *e = std::getenv("RT_PIPELINE")) { // 0 / 1: one frame at a time; n: n frames in flight
         const int n = std::atoi(e);
         c->framesInFlight = std::max(1, std::min(lanes, n <= 0 ? 1 : n));
+        c->lanesByCaller = true;
     }
     // Device address of the static scratch array on THIS device (each GPU holds its own copy): looked up once per
     // device, with that device current, and used from then on wherever host code needs the array's memory.
@@ -825,7 +837,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         // schedule candidates, not with the per-pixel side images (written early), not on a caller's stream.
         bool ours = false;
         for (int k = 0; k < c->lanesAvailable; ++k) ours = ours || c->stream == c->lane[k].stream;
-        const int lanes = std::min(c->framesInFlight, c->lanesAvailable);
+        const int lanes = lanesInUse(c);
         const size_t laneBytes = tilePixels * (size_t)n * rtWavefrontBytesPerPath();
         const bool pipelined = lanes > 1 && ours && c->lastWalkSettled &&
                                !(p->flags & (RT_FLAG_AUX | RT_FLAG_PIXEL_STATS)) &&

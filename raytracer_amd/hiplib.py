@@ -308,7 +308,8 @@ class Context:
         return int(lib().rt_frames_in_flight(self._h))
 
     def set_frames_in_flight(self, n):
-        """n > 1 (default 3): successive frames rotate over n internal streams; 1: one frame at a time."""
+        """n > 1 (default 4): successive frames rotate over n internal streams; 1: one frame at a time; 0: the launcher's
+        own choice again (4, or 3 for a scene beyond the L2 caches)."""
         self._check(lib().rt_set_frames_in_flight(self._h, int(n)), "rt_set_frames_in_flight")
 
     def flat_cells(self, which=0):
