@@ -890,7 +890,11 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
             const int entry = specLds[tableAt + rowLane];
             const unsigned vd = specLds[tableAt];                       // positions whose node exists
             const unsigned leafMask = specLds[tableAt + RT_SPEC_STRIDE - 1]; // positions whose node is a leaf
-            const int cand = rowLane == 0 ? next : min(entry, N - 1);   // (a missing node: any record, masked by vd)
+            int cand = rowLane == 0 ? next : min(entry, N - 1);   // (a missing node: any record, masked by vd)
+            unsigned vdNow = vd, leafNow = leafMask;
+            // (the three table reads have arrived once `cand` is known; saying so here keeps the compiler from waiting for
+            // them — and with them for the first half of the box — between the two reads of the box record)
+            asm volatile("" : "+v"(cand), "+v"(vdNow), "+v"(leafNow));
             const float4 b0 = rtLdsNodes[2 * cand], b1 = rtLdsNodes[2 * cand + 1];
             const int w1 = __float_as_int(b1.w);
             const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
@@ -901,7 +905,7 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
             const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
             // geometry.glsl:66-76 and the pruning test of trace3.cs:238-246
             const bool enter = maxt >= 0.0f && mint <= maxt * 1.00000024f && !(mint > nearest);
-            const unsigned go = (unsigned)(__ballot(enter) >> rowShift) & vd;
+            const unsigned go = (unsigned)(__ballot(enter) >> rowShift) & vdNow;
             if (iterations + 4 <= p.maxFollows) {
                 // the path of the reference's loop through the outcomes: from position q, "enter" leads to 2q+1, else 2q+2
                 const unsigned p1 = 2u - (go & 1u);
@@ -910,11 +914,11 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
                 const unsigned p4 = 2u * p3 + 2u - ((go >> p3) & 1u);
                 const unsigned pathMask = 1u | (1u << p1) | (1u << p2) | (1u << p3);
                 // it stops at the first position (positions grow along the path) that has no node or is an entered leaf
-                const unsigned stops = pathMask & (~vd | (go & leafMask));
+                const unsigned stops = pathMask & (~vdNow | (go & leafNow));
                 const int q = __ffs((int)stops) - 1; // -1: four decisions taken, none of them a stop
                 const unsigned upTo = q < 0 ? 0xFFFFFFFFu : ((2u << q) - 1u);
-                iterations += __popc(pathMask & vd & upTo);
-                const bool ended = q >= 0 && !((vd >> q) & 1u);
+                iterations += __popc(pathMask & vdNow & upTo);
+                const bool ended = q >= 0 && !((vdNow >> q) & 1u);
                 const int to = specLds[tableAt + (q < 0 ? (int)p4 : 2 * q + 1)]; // a leaf's successor, or four decisions on
                 next = (ended || to == 0xFFFF) ? -1 : to;
                 if (q >= 0 && !ended) {
@@ -928,7 +932,7 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
 #pragma unroll
                 for (int level = 0; level < 4; ++level) {
                     const bool walking = state == 0;
-                    const bool v = (vd >> pos) & 1u, g = (go >> pos) & 1u, f = g && ((leafMask >> pos) & 1u);
+                    const bool v = (vdNow >> pos) & 1u, g = (go >> pos) & 1u, f = g && ((leafNow >> pos) & 1u);
                     const bool over = iterations + 1 > p.maxFollows;
                     const bool visit = walking && v;
                     iterations += visit ? 1 : 0;
