@@ -72,6 +72,7 @@ struct rt_ctx {
     int lanesAvailable = 1;             // lanes whose stream and event could be created
     int framesInFlight = RT_DEFAULT_LANES; // lanes in use, 1 .. RT_MAX_LANES (rt_set_frames_in_flight, RT_PIPELINE)
     bool lanesByCaller = false;         // set by rt_set_frames_in_flight / RT_PIPELINE: then used as given; else scenes beyond the L2s get 3
+    int tuneExtendBlocksDense = 3;                   // ... for stages of at least 2 M rays (WfParams::extendBlocksDense)
     int tuneRefillLanes = 0, tuneExtendBlocks = 4;  // development knobs: RT_WF_REFILL (0: by scene size), RT_WF_BLOCKS
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
     int tuneWalkStop = 0, tuneWalkMin = 0;           // RT_WF_WALK_STOP (eighths), RT_WF_WALK_MIN: 0 = by scene size (WfParams::walkStop)
@@ -99,7 +100,7 @@ struct rt_ctx {
     int lastWalkStop = 0;      // what the most recent wavefront launch used ...
     bool lastWalkSettled = false; // ... and whether that was a settled choice (rt_walk_stop)
     int tuneMinRays = 4;                             // RT_WF_MIN_RAYS: floor of the rays-per-wave rule
-    int tuneCoopA = 8, tuneCoopB = 12;               // RT_WF_COOP_A / _B: the per-round rule of WfParams::coopA
+    int tuneCoopA = 6, tuneCoopB = 0;                // RT_WF_COOP_A / _B: the per-round rule of WfParams::coopA
     int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 2, tuneChunk = 64;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
     int tuneLongWalk = 0;                            // RT_WF_LONG_WALK (WfParams::longWalk)
     int tuneRowStaticK = 8, tuneRowChunkDiv = 2;     // RT_WF_ROW_STATIC, RT_WF_ROW_CHUNK_DIV (WfParams::rowStaticK / rowChunkDiv)

@@ -307,7 +307,7 @@ int rt_create(int device_id, rt_ctx **out) {
     if (const char *e = std::getenv("RT_WF_MIN_RAYS")) c->tuneMinRays = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_COOP_A")) c->tuneCoopA = std::atoi(e);
     if (const char *e = std::getenv("RT_WF_COOP_B")) c->tuneCoopB = std::atoi(e);
-    if (const char *e = std::getenv("RT_WF_BLOCKS")) c->tuneExtendBlocks = std::max(1, std::min(8, std::atoi(e)));
+    if (const char *e = std::getenv("RT_WF_BLOCKS")) c->tuneExtendBlocks = c->tuneExtendBlocksDense = std::max(1, std::min(8, std::atoi(e)));
     if (ensure(c, c->counters, sizeof(RtCountersDev) * RT_COUNTER_SHARDS) != RT_OK ||
         hipMemsetAsync(c->counters.p, 0, sizeof(RtCountersDev) * RT_COUNTER_SHARDS, c->stream) != hipSuccess) {
         (void)hipStreamDestroy(c->ownStream);
@@ -728,6 +728,8 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     }
     c->lastWalkStop = wp.walkStop;
     c->lastWalkSettled = !tuning || wt.state == 3;
+    // (the frames that time the schedule candidates must not differ in anything else)
+    wp.extendBlocksDense = c->lastWalkSettled ? c->tuneExtendBlocksDense : c->tuneExtendBlocks;
     wp.extendChunk = c->tuneChunk;
     // full waves test their leaves cooperatively when the triangles do not fit the L2s (measured on MI355X: the
     // coalesced triangle reads of that scheme win on the 1.7 M-triangle lattice, 3.66 -> 3.28 ms, and lose to

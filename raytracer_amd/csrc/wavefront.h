@@ -21,6 +21,7 @@ struct WfParams {
     int rowStaticK;         // row mode: queue entries per wave handed out by position before the shared cursor is used
     int rowChunkDiv;        // row mode: cursor chunk = remaining rays / (resident waves * rowChunkDiv), clamped to 4..64
     int extendBlocksPerCU; // persistent 256-thread blocks per CU of the extend kernel
+    int extendBlocksDense; // ... for a stage predicted to hold at least 2 M rays
     int extendCacheNodes;  // nodes the extend kernel keeps in LDS (32 bytes each, per block)
     int extendRaysPerWave; // 0 = chosen per launch from the queue size; 1..64 forces it (development knob)
     int extendFill;        // rays-per-wave rule: halve while (rays/2) * resident waves * extendFill >= queued rays

@@ -1157,7 +1157,7 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
     if (prof) rtMarkKernel(prof, RT_TIME_WF_PRIMARY, false);
 
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
-    const int logicBlocks = 256 * 4, extendBlocks = 256 * p.extendBlocksPerCU;
+    const int logicBlocks = 256 * 4;
     // the walk's node fetch is chosen here, once per launch (trace3_device.h: loadNodeT)
     const int extendNodes = !sc.packedLeaves ? NODES_ANY : scExtend.cacheNodes >= sc.numNodes ? NODES_PACKED_LDS : NODES_PACKED;
     auto extendKernel = extendNodes == NODES_ANY ? (wt ? rt_wf_extend_kernel<NODES_ANY, true> : rt_wf_extend_kernel<NODES_ANY, false>)
@@ -1169,6 +1169,13 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
     const int rowMode = rowsPossible ? p.rowMode : 0;
     const size_t rowLds = (size_t)sc.numNodes * (32 + 2 * RT_SPEC_STRIDE);
     const int rowBlocks = 256; // one 16-wave block per CU (80 VGPRs: a second one would not be resident)
+    // A frame whose stages hold many times more rays than there are ray slots keeps every wave busy to the end: three
+    // blocks per CU then do better than four (vector L1 and LDS per wave; room.obj 33.3 -> 32.2 ms, config #5 20.3 ->
+    // 19.8 ms), while the sparse stages of scene.obj want the four (one frame 1.64 vs 1.69 ms).  Decided per frame:
+    // mixing the two within a frame was slower than either (room.obj 36.3 ms).
+    bool dense = false;
+    if (predictedCounts)
+        for (int st = 1; st <= p.maxBounces && st < 32; ++st) dense = dense || 3ll * predictedCounts[st] >= (1ll << 21);
     auto extend = [&](int stage) {
         // rowMode 2: a stage that held few rays in the previous frame is bound by its longest walks, not by throughput
         bool rows = rowMode == 1;
@@ -1176,6 +1183,7 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
             const long long rays = (long long)predictedCounts[stage] * (stage == 0 ? 1 : 3);
             rows = rays > 0 && rays <= p.rowMaxRays;
         }
+        const int extendBlocks = 256 * (dense ? p.extendBlocksDense : p.extendBlocksPerCU);
         const int kind = rows ? RT_TIME_WF_EXTEND_ROWS : RT_TIME_WF_EXTEND;
         if (prof) rtMarkKernel(prof, kind, true);
         if (rows)
