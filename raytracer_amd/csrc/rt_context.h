@@ -101,7 +101,7 @@ struct rt_ctx {
     bool lastWalkSettled = false; // ... and whether that was a settled choice (rt_walk_stop)
     int tuneMinRays = 4;                             // RT_WF_MIN_RAYS: floor of the rays-per-wave rule
     int tuneCoopA = 6, tuneCoopB = 0;                // RT_WF_COOP_A / _B: the per-round rule of WfParams::coopA
-    int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 2, tuneChunk = 64;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
+    int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 0, tuneChunk = 64;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
     int tuneLongWalk = 0;                            // RT_WF_LONG_WALK (WfParams::longWalk)
     int tuneRowStaticK = 8, tuneRowChunkDiv = 2;     // RT_WF_ROW_STATIC, RT_WF_ROW_CHUNK_DIV (WfParams::rowStaticK / rowChunkDiv)
     int tuneRowMode = -1, tuneRowMaxRays = -1;       // RT_WF_ROWS (0 never, 1 always, 2 per stage by ray count), RT_WF_ROW_MAX_RAYS
