@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
     c.rays = c.visits = c.tests = c.shaded = 0;
     c.lastIterations = 0;
     unsigned primaryVisits = 0, primaryTests = 0;
+    fillNodeCache(sc); // the top of the tree (all of it for the named scenes) in LDS: trace3_device.h, loadNode
 
     if (active) {
         const int W = img.width, H = img.height;
@@ -142,6 +143,9 @@ hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace
     const int ntiles = tilesX * tilesY;
     const int nblocks = ((ntiles + 7) / 8) * 8; // multiple of 8 so that the XCD re-map is a bijection
     auto kernel = (p.flags & RT_FLAG_WATERTIGHT) ? rt_trace3_kernel<true> : rt_trace3_kernel<false>;
-    hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(256), 0, stream, sc, img, p, tile, tilesX, tilesY, xcdRemap, counters);
+    RtScene cached = sc;
+    cached.cacheNodes = sc.packedLeaves ? (sc.numNodes < 896 ? sc.numNodes : 896) : 0;
+    hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(256), (size_t)cached.cacheNodes * 32, stream, cached, img, p, tile, tilesX,
+                       tilesY, xcdRemap, counters);
     return hipGetLastError();
 }

@@ -359,6 +359,7 @@ __global__ __launch_bounds__(256) void rt_trace3_rl_kernel(RtScene sc, RtQTable 
     c.rays = c.visits = c.tests = c.shaded = 0;
     c.lastIterations = 0;
     unsigned updates = 0, primaryVisits = 0, primaryTests = 0;
+    fillNodeCache(sc); // the top of the tree (all of it for the named scenes) in LDS: trace3_device.h, loadNode
 
     if (active) {
         const int W = img.width, H = img.height;
@@ -470,7 +471,9 @@ hipError_t rtLaunchTrace3RL(const RtScene &sc, const RtQTable &q, const RtImages
         const char *e = getenv("RT_RL_MODE"); // diagnostics: bit set of RL_MODE_*
         return e ? atoi(e) : (RL_MODE_GROUP_VISITS | RL_MODE_GROUP_Q);
     }();
-    hipLaunchKernelGGL(rt_trace3_rl_kernel, dim3(tilesX * tilesY), dim3(256), 0, stream, sc, q, img, p, tile, tilesX, mode,
-                       counters);
+    RtScene cached = sc;
+    cached.cacheNodes = sc.packedLeaves ? (sc.numNodes < 896 ? sc.numNodes : 896) : 0;
+    hipLaunchKernelGGL(rt_trace3_rl_kernel, dim3(tilesX * tilesY), dim3(256), (size_t)cached.cacheNodes * 32, stream, cached, q,
+                       img, p, tile, tilesX, mode, counters);
     return hipGetLastError();
 }
