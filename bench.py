@@ -76,7 +76,7 @@ def cpu_baseline(wl, spp, max_bounces, filter_iters, max_follows=1000, budget_s=
 
 
 def alone_roofline(K, ctx, step, steps, wl, W, H, spp, filter_iters, scene_key, root_misses):
-    """The timed region runs with two frames in flight, so its kernel spans are the durations of launches that
+    """The timed region runs with several frames in flight (four by default), so its kernel spans are the durations of launches that
     share the GPU with the other frame's.  This measures the same kernel once more with one frame at a time
     (outside the timed region): what a launch that has the GPU to itself achieves."""
     ctx.sync()
