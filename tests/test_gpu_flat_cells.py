@@ -39,6 +39,34 @@ def cells_of(img, W, H):
     return out
 
 
+def expected_levels(flags, color, normal, pos, W, H, passes):
+    """rt_flat_levels_kernel restated (filter_kernel.hip): a cell is good when it is flat and equal to its flat right and
+    upper neighbours; it has level > i when the cells within ceil(S_i / 16) of it are all good and its pixels' reach
+    S_i = 1 + 3 + ... + (2^(i+1) - 1) stays inside the image."""
+    cy, cx = flags.shape
+    tex = np.concatenate([np.ascontiguousarray(a).view(np.uint8).reshape(H, W, -1)[::16, ::16][:cy, :cx]
+                          for a in (color, normal, pos)], axis=-1)
+    flat = flags.astype(bool)
+    good = flat.copy()
+    same_r = (tex[:, :-1] == tex[:, 1:]).all(-1)
+    same_u = (tex[:-1] == tex[1:]).all(-1)
+    good[:, :-1] &= ~flat[:, 1:] | same_r
+    good[:-1] &= ~flat[1:] | same_u
+    levels = np.zeros((cy, cx), np.uint8)
+    for j in range(cy):
+        for i in range(cx):
+            reach = 0
+            for k in range(passes):
+                reach += (2 << k) - 1
+                if 16 * i - reach < 0 or 16 * j - reach < 0 or 16 * i + 15 + reach >= W or 16 * j + 15 + reach >= H:
+                    break
+                r = (reach + 15) // 16
+                if j - r < 0 or i - r < 0 or j + r >= cy or i + r >= cx or not good[j - r:j + r + 1, i - r:i + r + 1].all():
+                    break
+                levels[j, i] = k + 1
+    return levels
+
+
 def same_bits(a, b):
     return np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
 
@@ -65,6 +93,8 @@ def test_filter_with_the_record_equals_filter_without(W, H, iters):
             # from the geometry and the image edge there are such cells (each pass reaches further: small images have none)
             levels = on.flat_cells(1)
             assert levels is not None and levels.max() <= iters and not (levels.astype(bool) & ~flags.astype(bool)).any()
+            assert np.array_equal(levels, expected_levels(flags, on.readback(hiplib.IMAGE_COLOR), on.readback(hiplib.IMAGE_NORMAL),
+                                                          on.readback(hiplib.IMAGE_POSITION), W, H, iters))
             done = levels == iters
             assert done.sum() > 0 or W < 900
             flat_out = cells_of(on.readback(hiplib.IMAGE_FILTERED), W, H)
