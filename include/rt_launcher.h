@@ -17,7 +17,10 @@
  *   rt_readback      ← glGetTexImage                              (reference src/FrameBuffer.cpp:89-99)
  *
  * Plain pointers and sizes only.  One rt_ctx per GPU; a context is not thread-safe.  All work is
- * queued on one HIP stream; rt_sync and rt_readback are the only blocking calls.
+ * queued asynchronously: on the context's own HIP stream (or the caller's, rt_set_stream), successive
+ * wavefront frames by turns on up to four internal streams ordered among themselves and with every
+ * other entry point by events on the device (rt_set_frames_in_flight), the multi-GPU gather on one
+ * more.  rt_sync, rt_readback and the other calls marked "blocking" are the only ones that wait.
  * Every function returns 0 on success or a negative RT_E* code; rt_last_error gives the text.
  * Images are stored row 0 = bottom row, like the GL images they replace.
  *
@@ -269,6 +272,28 @@ int rt_gather_tiles(rt_ctx *ctx, int image, const rt_rect *rects, int nrects, in
  * 0 = none yet, or that launch was one of the first frames after an upload / resize on which the launcher still times
  * its two candidates; else the walkStop in use (eighths of the walking lanes; 8 = every lane walks to its leaf). */
 int rt_walk_stop(const rt_ctx *ctx);
+
+/* What the most recent rt_trace / rt_trace_batch / rt_trace_batch_static of RT_KERNEL_TRACE3 that ran the wavefront
+ * pipeline was launched with (no counterpart in the reference; for tests and benchmarks that must know WHICH kernels and
+ * which schedule produced a picture — none of these choices may change it).  `size` must be set by the caller. */
+typedef struct rt_schedule_info {
+    uint32_t size;
+    int32_t pipelined;        /* 1: the frame ran on a lane of its own with a staged G-buffer (frames in flight)        */
+    int32_t lane;             /* index of that lane                                                                  */
+    int32_t frames_in_flight; /* lanes the launcher rotates over                                                     */
+    int32_t stages;           /* extend launches of the frame (maxBounces + 1)                                       */
+    int32_t rows_stage_mask;  /* bit s set: stage s ran in rt_wf_extend_rows_kernel (one ray per 16 lanes)            */
+    int32_t have_prediction;  /* 1: queue sizes of an earlier frame of the same shape chose the kernels               */
+    int32_t dense;            /* 1: predicted >= 2 M rays in a stage -> extend_blocks_per_cu is the dense setting     */
+    int32_t extend_blocks_per_cu;
+    int32_t walk_stop;        /* as rt_walk_stop, but also while unsettled                                           */
+    int32_t walk_settled;
+    int32_t fill;             /* rays-per-wave rule of sparse stages (WfParams::extendFill)                          */
+    int32_t node_fetch;       /* 0 general records, 1 packed records, 2 packed + whole tree in LDS                   */
+    int32_t flat_record;      /* 1: the frame's last kernel kept the flat-cell record                                */
+    int32_t static_scratch;   /* 1: rt_trace_batch_static                                                            */
+} rt_schedule_info;
+int rt_last_schedule(const rt_ctx *ctx, rt_schedule_info *out);
 
 /* Frames in flight (no counterpart in the reference, whose GL queue is one stream): with n > 1 (default 4), successive
  * rt_trace_batch calls of RT_KERNEL_TRACE3 rotate over n internal streams ("lanes"), each with its own pipeline memory:

@@ -243,3 +243,24 @@ def filter_passes(color, normal, pos, iterations, c_phi0=3.3, n_phi0=1e-2, p_phi
         outs.append(out.view(np.float16))
         read, is_f32 = out, 0
     return outs
+
+
+def filter_pass(read, normal, pos, i, c_phi0=3.3, n_phi0=1e-2, p_phi0=5.5):
+    """Pass i (0-based) of Filter::filter on its own: `read` is the tracer's RGBA32F colour (i == 0 reads float32) or the
+    RGBA16F output of pass i-1 (float16 / uint16 bits).  Lets a test check a pass against the oracle on the SAME input
+    the GPU pass had, so that one-step differences of earlier passes do not add up."""
+    L = lib()
+    h, w = read.shape[:2]
+    is_f32 = 1 if read.dtype == np.float32 else 0
+    read = np.ascontiguousarray(read) if is_f32 else np.ascontiguousarray(read).view(np.uint16)
+    normal = np.ascontiguousarray(normal, np.int8)
+    pos = np.ascontiguousarray(pos).view(np.uint16)
+    f = np.float32
+    with np.errstate(divide="ignore"):
+        c_phi = f(1.0) / f(i) * f(c_phi0)
+    p_phi = f(1.0) / f(1 << i) * f(p_phi0)
+    n_phi = f(1.0) / f(1 << i) * f(n_phi0)
+    out = np.zeros((h, w, 4), np.uint16)
+    L.orc_filter_pass(w, h, read.ctypes.data, is_f32, normal.ctypes.data, pos.ctypes.data, out.ctypes.data,
+                      float(c_phi), float(n_phi), float(p_phi), (1 << (i + 1)) - 1)
+    return out.view(np.float16)

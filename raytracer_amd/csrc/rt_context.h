@@ -97,6 +97,7 @@ struct rt_ctx {
     hipEvent_t chainEvent = nullptr;    // the stop event recorded last, if nothing was enqueued after it: the next
     bool chainValid = false;            // span starts there instead of recording an event of its own (3 us each)
     long long pendingKey = -1;          // ... and the read-back in flight
+    rt_schedule_info lastSchedule = {}; // rt_last_schedule
     int lastWalkStop = 0;      // what the most recent wavefront launch used ...
     bool lastWalkSettled = false; // ... and whether that was a settled choice (rt_walk_stop)
     int tuneMinRays = 4;                             // RT_WF_MIN_RAYS: floor of the rays-per-wave rule

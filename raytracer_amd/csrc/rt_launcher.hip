@@ -187,7 +187,7 @@ void rtMarkKernel(void *opaque, int kind, bool begin) {
 
 extern "C" {
 
-const char *rt_version(void) { return "raytracer_amd gfx950 launcher 0.2 (round 2)"; }
+const char *rt_version(void) { return "raytracer_amd gfx950 launcher 0.3 (round 3)"; }
 
 void rt_work_group_size(int kernel, int out_xyz[3]) {
     (void)kernel;
@@ -200,6 +200,13 @@ void rt_work_group_size(int kernel, int out_xyz[3]) {
 int rt_walk_stop(const rt_ctx *c) {
     if (!c) return 0;
     return c->lastWalkSettled ? c->lastWalkStop : 0;
+}
+
+int rt_last_schedule(const rt_ctx *c, rt_schedule_info *out) {
+    if (!c || !out || out->size != sizeof(rt_schedule_info)) return RT_EINVAL;
+    if (c->lastSchedule.size == 0) return RT_ESTATE; // no wavefront frame yet
+    *out = c->lastSchedule;
+    return RT_OK;
 }
 
 size_t rt_image_pixel_bytes(int image) {
@@ -729,10 +736,13 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         }
         wp.walkStop = wt.state == 2 ? 1 : wt.state == 3 ? wt.choice : 8;
     }
-    c->lastWalkStop = wp.walkStop;
-    c->lastWalkSettled = !tuning || wt.state == 3;
+    const bool settled = !tuning || wt.state == 3;
+    if (!noAlloc) { // (the no-allocation entry point neither tunes nor speaks for the frames that do)
+        c->lastWalkStop = wp.walkStop;
+        c->lastWalkSettled = settled;
+    }
     // (the frames that time the schedule candidates must not differ in anything else)
-    wp.extendBlocksDense = c->lastWalkSettled ? c->tuneExtendBlocksDense : c->tuneExtendBlocks;
+    wp.extendBlocksDense = settled ? c->tuneExtendBlocksDense : c->tuneExtendBlocks;
     wp.extendChunk = c->tuneChunk;
     // full waves test their leaves cooperatively when the triangles do not fit the L2s (measured on MI355X: the
     // coalesced triangle reads of that scheme win on the 1.7 M-triangle lattice, 3.66 -> 3.28 ms, and lose to
@@ -766,9 +776,29 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     const bool profiled = c->profile && !noAlloc;
     rt_ctx *spanCtx = c;
     SpanGuard span(spanCtx, TK_TRACE, profiled);
+    WfScheduleOut chosen = {};
     hipError_t e = rtLaunchWavefront(sc, img, wp, wf, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream, beforeCommit,
-                                     profiled ? c : nullptr, predicted);
+                                     profiled ? c : nullptr, predicted, &chosen);
     span.end();
+    {
+        rt_schedule_info &si = c->lastSchedule;
+        si = rt_schedule_info{};
+        si.size = sizeof si;
+        si.pipelined = beforeCommit ? 1 : 0;
+        si.lane = beforeCommit ? c->laneNow : 0;
+        si.frames_in_flight = beforeCommit ? std::min(c->framesInFlight, c->lanesAvailable) : 1;
+        si.stages = p->maxBounces + 1;
+        si.rows_stage_mask = chosen.rowsStageMask;
+        si.have_prediction = predicted ? 1 : 0;
+        si.dense = chosen.dense;
+        si.extend_blocks_per_cu = chosen.extendBlocksPerCU;
+        si.walk_stop = wp.walkStop;
+        si.walk_settled = settled ? 1 : 0;
+        si.fill = wp.extendFill;
+        si.node_fetch = chosen.nodeFetch;
+        si.flat_record = wf.flat.flag ? 1 : 0;
+        si.static_scratch = noAlloc ? 1 : 0;
+    }
     if (e == hipSuccess && !c->countsPending) { // (one read-back in flight at a time: hostCounts is a single buffer)
         if (hipMemcpyAsync(c->hostCounts, wf.counts, 32 * sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
             hipEventRecord(c->countsEvent, c->stream) == hipSuccess) {
@@ -844,7 +874,11 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         for (int k = 0; k < c->lanesAvailable; ++k) ours = ours || c->stream == c->lane[k].stream;
         const int lanes = lanesInUse(c);
         const size_t laneBytes = tilePixels * (size_t)n * rtWavefrontBytesPerPath();
-        const bool pipelined = lanes > 1 && ours && c->lastWalkSettled &&
+        // (a frame on which the launcher times a schedule candidate runs alone: decided for the COMING frame, not from
+        // what the last call — possibly a small tile, or the no-allocation entry point — left behind)
+        const bool willTune = c->tuneWalkStop == 0 && hot <= (size_t)3 * 1024 * 1024 && p->maxBounces >= 1 &&
+                              tilePixels * (size_t)n >= ((size_t)1 << 20) && c->walkTune.state != 3;
+        const bool pipelined = lanes > 1 && ours && !willTune &&
                                !(p->flags & (RT_FLAG_AUX | RT_FLAG_PIXEL_STATS)) &&
                                laneBytes * (size_t)lanes <= ((size_t)48 << 30);
         hipEvent_t before = nullptr;

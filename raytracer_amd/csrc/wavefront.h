@@ -66,13 +66,17 @@ struct WfBuffers {
     int tilePixels;
 };
 
+struct WfScheduleOut { // what rtLaunchWavefront decided (rt_last_schedule)
+    int rowsStageMask, dense, extendBlocksPerCU, nodeFetch;
+};
+
 // predictedCounts: queue sizes per stage of a similar earlier frame (32 ints), or null when there is none
 // beforeCommit: an event the stream waits for before the blend kernel (the only kernel that writes caller-visible
 // images when the G-buffer is staged), or null
 hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfParams &p, const WfBuffers &wf,
                              const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream,
                              hipEvent_t beforeCommit,
-                             void *profileCtx, const int *predictedCounts);
+                             void *profileCtx, const int *predictedCounts, WfScheduleOut *chosen = nullptr);
 void rtMarkKernel(void *ctxOpaque, int kind, bool begin);
 // bytes of device memory per unit of capacity (one path slot) and per (sample, tile pixel)
 size_t rtWavefrontBytesPerPath();

@@ -1132,7 +1132,7 @@ size_t rtWavefrontBytesPerPath() { return 6 * 16 + 8 + 16 + 3 * (4 * 16 + 16 + 8
 
 hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const WfParams &p, const WfBuffers &wf,
                              const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream,
-                             hipEvent_t beforeCommit, void *prof, const int *predictedCounts) {
+                             hipEvent_t beforeCommit, void *prof, const int *predictedCounts, WfScheduleOut *chosen) {
     const int tw = tile.x1 - tile.x0, th = tile.y1 - tile.y0;
     if (tw <= 0 || th <= 0 || p.batch <= 0) return hipSuccess;
     RtImages img = imgOut; // what the kernels before the blend write: the staged G-buffer when there is one
@@ -1176,6 +1176,12 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
     bool dense = false;
     if (predictedCounts)
         for (int st = 1; st <= p.maxBounces && st < 32; ++st) dense = dense || 3ll * predictedCounts[st] >= (1ll << 21);
+    if (chosen) {
+        chosen->rowsStageMask = 0;
+        chosen->dense = dense ? 1 : 0;
+        chosen->extendBlocksPerCU = dense ? p.extendBlocksDense : p.extendBlocksPerCU;
+        chosen->nodeFetch = extendNodes == NODES_ANY ? 0 : extendNodes == NODES_PACKED ? 1 : 2;
+    }
     auto extend = [&](int stage) {
         // rowMode 2: a stage that held few rays in the previous frame is bound by its longest walks, not by throughput
         bool rows = rowMode == 1;
@@ -1185,6 +1191,7 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
         }
         const int extendBlocks = 256 * (dense ? p.extendBlocksDense : p.extendBlocksPerCU);
         const int kind = rows ? RT_TIME_WF_EXTEND_ROWS : RT_TIME_WF_EXTEND;
+        if (chosen && rows && stage < 31) chosen->rowsStageMask |= 1 << stage;
         if (prof) rtMarkKernel(prof, kind, true);
         if (rows)
             hipLaunchKernelGGL(rt_wf_extend_rows_kernel, dim3(rowBlocks), dim3(1024), rowLds, stream, sc, p, wf, stage,

@@ -66,11 +66,21 @@ class Timings(ctypes.Structure):
         return {n: (self.ms[i], int(self.launches[i])) for i, n in enumerate(TIME_NAMES) if self.launches[i]}
 
 
+class ScheduleInfo(ctypes.Structure):
+    """rt_schedule_info (include/rt_launcher.h)."""
+    _fields_ = [("size", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
+        "pipelined", "lane", "frames_in_flight", "stages", "rows_stage_mask", "have_prediction", "dense",
+        "extend_blocks_per_cu", "walk_stop", "walk_settled", "fill", "node_fetch", "flat_record", "static_scratch")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_[1:]}
+
+
 EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_upload", "rt_set_table", "rt_download", "rt_resize",
            "rt_clear", "rt_trace", "rt_trace_batch", "rt_trace_batch_static", "rt_static_max_paths", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
            "rt_readback_rect_device", "rt_write_rect_device", "rt_write_rect_device_async", "rt_write_image", "rt_image_pixel_bytes",
            "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
-           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_gather_tiles", "rt_walk_stop", "rt_set_frames_in_flight", "rt_frames_in_flight", "rt_flat_cells",
+           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_gather_tiles", "rt_walk_stop", "rt_last_schedule", "rt_set_frames_in_flight", "rt_frames_in_flight", "rt_flat_cells",
            "rt_work_group_size", "rt_version"]
 
 _lib = None
@@ -120,6 +130,7 @@ def lib():
         L.rt_comm_destroy.argtypes = [vp]
         L.rt_gather_tiles.argtypes = [vp, i32, rp, i32, i32]
         L.rt_walk_stop.argtypes = [vp]
+        L.rt_last_schedule.argtypes = [vp, ctypes.POINTER(ScheduleInfo)]
         L.rt_set_frames_in_flight.argtypes = [vp, i32]
         L.rt_frames_in_flight.argtypes = [vp]
         L.rt_flat_cells.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t]
@@ -303,6 +314,16 @@ class Context:
 
     def walk_stop(self):
         return int(lib().rt_walk_stop(self._h))
+
+    def last_schedule(self):
+        """rt_last_schedule: how the most recent wavefront frame was launched (None before the first)."""
+        si = ScheduleInfo()
+        si.size = ctypes.sizeof(ScheduleInfo)
+        r = lib().rt_last_schedule(self._h, ctypes.byref(si))
+        if r == -4:  # RT_ESTATE
+            return None
+        self._check(r, "rt_last_schedule")
+        return si
 
     def frames_in_flight(self):
         return int(lib().rt_frames_in_flight(self._h))

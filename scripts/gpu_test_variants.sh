@@ -9,3 +9,7 @@ RT_WF_WALK_STOP=3 RT_WF_WALK_MIN=1 RT_WF_REFILL=32 RT_WF_COOP=1 RT_WF_PRIMARY_VI
   timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread | tail -2
 RT_WF_WALK_STOP=1 RT_WF_WALK_MIN=40 RT_WF_MIN_RAYS=1 RT_WF_REFILL=8 \
   timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread | tail -2
+# (3) every extend stage in the row-mode kernel (one ray per 16 lanes; tests/test_gpu_timed_config.py compares the two
+# kernels case by case, this runs the WHOLE parity suite on rt_wf_extend_rows_kernel)
+RT_WF_ROWS=1 \
+  timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread | tail -2

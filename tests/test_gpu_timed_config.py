@@ -1,0 +1,253 @@
+"""The kernels and the schedule that bench.py TIMES, against the oracle ("what's weak" 1).
+
+tests/test_gpu_parity.py renders through `render()`: a fresh rt_resize (no queue-size prediction yet), the per-pixel
+side images (RT_FLAG_AUX | RT_FLAG_PIXEL_STATS: frames in flight off).  That leaves out what a run of frames uses:
+  * rt_wf_extend_rows_kernel (one ray per 16-lane row, speculative four-decision walk, DPP row minimum) — chosen per
+    stage from the previous frame's queue sizes, or for every stage with RT_WF_ROWS=1;
+  * flags 0, four frames in flight on four lanes with staged G-buffers, fill 1, the flat-cell record in the filter,
+    three extend blocks per CU on dense frames.
+Here both are compared with the CPU oracle (oracle/rt_oracle.c, pinned by the llvmpipe fixtures) and the llvmpipe
+fixtures directly, and rt_last_schedule / the rows_* counters assert that those kernels really ran.
+Visit order to match: reference src/shaders/trace3.cs:216-278."""
+import glob
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from raytracer_amd import hiplib, workloads
+from tests.util import GOLDEN, assert_radiance_close, half_ulp_diff, load_npz
+
+pytestmark = pytest.mark.gpu
+
+TRACE = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "trace_*.npz")))
+IDS = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "ids_*.npz")))
+SIDE = hiplib.FLAG_AUX | hiplib.FLAG_PIXEL_STATS
+ALL_IMAGES = dict(color=hiplib.IMAGE_COLOR, normal=hiplib.IMAGE_NORMAL, pos=hiplib.IMAGE_POSITION,
+                  tridx=hiplib.IMAGE_TRIDX, visits=hiplib.IMAGE_VISITS, stats=hiplib.IMAGE_STATS)
+
+
+def make_ctx(**env):
+    """A context created under the given environment (the launcher reads its knobs in rt_create)."""
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return hiplib.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="module")
+def rows():
+    c = make_ctx(RT_WF_ROWS=1)      # every extend stage in rt_wf_extend_rows_kernel
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def lanes():
+    c = make_ctx(RT_WF_ROWS=0)      # every extend stage in rt_wf_extend_kernel
+    yield c
+    c.close()
+
+
+def render(ctx, wl, spp, mb, flags=SIDE, **kw):
+    ctx.upload_scene(wl.buffers)
+    ctx.resize(wl.width, wl.height)
+    ctx.reset_counters()
+    ctx.trace_samples(wl.rays, wl.eye, spp=spp, max_bounces=mb, flags=flags, num_emitters=wl.num_emitters, **kw)
+    out = {k: ctx.readback(v) for k, v in ALL_IMAGES.items()}
+    c = ctx.counters()
+    out["counters"] = (c.rays, c.node_visits, c.tri_tests, c.shaded_hits, c.paths, c.primary_node_visits, c.primary_tri_tests)
+    out["rows"] = (c.rows_rays, c.rows_node_visits, c.rows_tri_tests)
+    out["schedule"] = ctx.last_schedule().as_dict()
+    return out
+
+
+def oracle_render(wl, spp, mb, **kw):
+    from oracle import orclib
+    return orclib.trace(orclib.Scene(wl.buffers), wl.width, wl.height, wl.rays, wl.eye, spp=spp, max_bounces=mb, **kw)
+
+
+def assert_ids_equal(got, ref):
+    assert np.array_equal(got["tridx"], ref["tridx"])
+    assert np.array_equal(got["visits"], ref["visits"])
+    assert np.array_equal(got["normal"], ref["normal"])
+    assert np.array_equal(got["pos"].view(np.uint16), np.asarray(ref["pos"]).view(np.uint16))
+
+
+def assert_ran_in_rows(got, mb):
+    """Every stage of the frame ran in the row-mode kernel: all traversals but the root-box misses (classify kernel)."""
+    assert got["schedule"]["rows_stage_mask"] == (1 << (mb + 1)) - 1, got["schedule"]
+    rays, visits, tests = got["counters"][:3]
+    # the classify kernel finishes the pixels whose primary ray misses the root box: one ray of one visit each, no test
+    root_misses = rays - got["rows"][0]
+    assert 0 <= root_misses <= int(((got["tridx"] < 0) & (got["visits"] == 1)).sum())
+    assert got["rows"][0] >= int((got["tridx"] >= 0).sum()) and got["rows"][0] > 0
+    assert got["rows"] == (rays - root_misses, visits - root_misses, tests)
+
+
+def assert_same_bits(a, b):
+    for k in ALL_IMAGES:
+        assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
+    assert a["counters"] == b["counters"]
+
+
+# ------------------------------------------------------------------------------------------------ (a) row mode
+@pytest.mark.parametrize("name", TRACE)
+def test_row_mode_against_llvmpipe_fixture(rows, lanes, name):
+    g = load_npz(name)
+    m = g["meta"]
+    wl = workloads.Workload(m["scene"], m["width"], m["height"])
+    got = render(rows, wl, m["spp"], m["max_bounces"])
+    assert_ran_in_rows(got, m["max_bounces"])
+    assert_ids_equal(got, g)
+    assert (got["stats"][..., 0] != g["stats"][..., 0]).mean() < 5e-3
+    assert_radiance_close(g["color"], got["color"], name)
+    other = render(lanes, wl, m["spp"], m["max_bounces"])
+    assert other["schedule"]["rows_stage_mask"] == 0 and other["rows"] == (0, 0, 0)
+    assert_same_bits(got, other)
+
+
+@pytest.mark.parametrize("name", IDS)
+def test_row_mode_full_size_ids_against_llvmpipe_fixture(rows, name):
+    """BASELINE.json configs[0..2] at their full sizes with the primary rays walked by the row-mode kernel."""
+    g = load_npz(name)
+    m = g["meta"]
+    wl = workloads.Workload(m["scene"], m["width"], m["height"])
+    got = render(rows, wl, 1, 0, flags=hiplib.FLAG_AUX)
+    assert got["schedule"]["rows_stage_mask"] == 1 and got["rows"][0] > 0
+    assert np.array_equal(got["tridx"], g["tridx"].astype(np.int32))
+    assert np.array_equal(got["visits"], g["visits"].astype(np.int32))
+    for k in ("tridx", "visits", "normal", "pos"):
+        assert hashlib.sha256(got[k].tobytes()).hexdigest() == m[k + "_sha256"], k
+    rays, visits, tests = got["counters"][:3]
+    assert rays == m["width"] * m["height"] and visits == m["visits_sum"] and tests == m["tests_sum"]
+
+
+@pytest.mark.parametrize("scene,w,h,spp,mb", [("room", 200, 150, 3, 5), ("scene", 320, 180, 4, 5),
+                                               ("suzanne", 256, 144, 2, 1), ("teapot", 160, 120, 1, 4),
+                                               ("room", 33, 17, 1, 5)])
+def test_row_mode_against_oracle(rows, lanes, scene, w, h, spp, mb):
+    wl = workloads.Workload(scene, w, h)
+    got = render(rows, wl, spp, mb)
+    assert_ran_in_rows(got, mb)
+    ref = oracle_render(wl, spp, mb)
+    assert_ids_equal(got, ref)
+    assert_radiance_close(ref["color"], got["color"], f"rows {scene} {w}x{h}")
+    assert_same_bits(got, render(lanes, wl, spp, mb))
+
+
+@pytest.mark.parametrize("max_follows", [1, 2, 3, 4, 5, 17, 18, 19, 20, 21, 22, 23, 24])
+def test_row_mode_max_follows_abort(rows, lanes, max_follows):
+    """MAX_FOLLOWS (trace3.cs:227-234) lands inside a four-decision round of the speculative walk for most of these
+    values: the kernel then takes its decision-by-decision fallback (wavefront.hip, `iterations + 4 > maxFollows`) and the
+    abort must land on the reference's node."""
+    wl = workloads.Workload("room", 48, 32)
+    got = render(rows, wl, 1, 1, max_follows=max_follows)
+    assert_ran_in_rows(got, 1)
+    ref = oracle_render(wl, 1, 1, max_follows=max_follows)
+    assert_ids_equal(got, ref)
+    aborted = got["visits"] == max_follows + 1
+    assert aborted.any() and (got["tridx"][aborted] == -1).all()
+    assert_radiance_close(ref["color"], got["color"], f"rows max_follows {max_follows}")
+    assert_same_bits(got, render(lanes, wl, 1, 1, max_follows=max_follows))
+
+
+# ------------------------------------------------------------------------------------------------ (b), (c) bench shape
+def bench_shape(scene, frames, want_dense):
+    """bench.py's timed region: rt_trace_batch (4 samples, flags 0) + rt_filter(5) per frame, queued back to back without
+    a sync, after the launcher has settled its schedule — here with frames that ACCUMULATE (sample index keeps counting,
+    so frame k blends onto frame k-1's colour across lanes), compared with the oracle's 4 * frames samples."""
+    from oracle import orclib
+    W, H, spp, mb, iters = 1920, 1080, 4, 5, 5
+    wl = workloads.Workload(scene, W, H)
+    ctx = make_ctx()
+    try:
+        ctx.upload_scene(wl.buffers)
+        ctx.resize(W, H)
+
+        def frame(k):
+            ctx.trace_samples(wl.rays, wl.eye, spp=spp, frame0=spp * k, max_bounces=mb, flags=0, num_emitters=wl.num_emitters)
+            ctx.filter(iters)
+
+        settle = 0
+        while ctx.walk_stop() == 0 and settle < 8:     # as bench.py: the first frames time the two walk schedules
+            frame(0)
+            settle += 1
+        assert ctx.walk_stop() != 0
+        for _ in range(3):                              # warm-up: the queue sizes of these frames choose the kernels below
+            frame(0)
+        ctx.sync()
+        ctx.clear()
+        ctx.reset_counters()
+        schedules = []
+        for k in range(frames):                         # back to back, no sync
+            frame(k)
+            schedules.append(ctx.last_schedule().as_dict())
+        got = {k: ctx.readback(v) for k, v in dict(color=hiplib.IMAGE_COLOR, normal=hiplib.IMAGE_NORMAL,
+                                                   pos=hiplib.IMAGE_POSITION, filtered=hiplib.IMAGE_FILTERED).items()}
+        cnt = ctx.counters()
+        levels = ctx.flat_cells(1)
+        in_flight = ctx.frames_in_flight()
+        # every filter pass on its own against the oracle, on the input the GPU pass had (the output of the pass before)
+        read = got["color"]
+        for i in range(iters):
+            ctx.filter(i + 1)
+            mine = ctx.readback(hiplib.IMAGE_FILTERED)
+            want = orclib.filter_pass(read, got["normal"], got["pos"], i).view(np.uint16)
+            d = half_ulp_diff(want, mine.view(np.uint16))
+            assert d.max() <= 1 and (d == 0).mean() > 0.995, (scene, i, int(d.max()), float((d == 0).mean()))
+            read = mine
+        assert np.array_equal(read.view(np.uint16), got["filtered"].view(np.uint16))   # the same chain as the queued one
+    finally:
+        ctx.close()
+    # --- the schedule that ran is the timed one
+    assert in_flight == 4
+    for s in schedules:
+        assert s["pipelined"] == 1 and s["frames_in_flight"] == 4 and s["walk_settled"] == 1, s
+        assert s["have_prediction"] == 1 and s["fill"] == 1 and s["flat_record"] == 1 and s["node_fetch"] == 2, s
+        assert s["stages"] == mb + 1
+        if want_dense:
+            assert s["dense"] == 1 and s["extend_blocks_per_cu"] == 3, s
+        else:
+            assert s["dense"] == 0 and s["extend_blocks_per_cu"] == 4 and s["rows_stage_mask"] != 0, s
+    assert sorted({s["lane"] for s in schedules}) == list(range(min(4, frames)))
+    if not want_dense:
+        assert cnt.rows_rays > 0 and cnt.rows_node_visits > 0 and cnt.rows_tri_tests > 0
+    assert levels is not None
+    # --- the picture is the oracle's
+    ref = orclib.trace(orclib.Scene(wl.buffers), W, H, wl.rays, wl.eye, spp=spp * frames, max_bounces=mb)
+    assert np.array_equal(got["normal"], ref["normal"])
+    assert np.array_equal(got["pos"].view(np.uint16), np.asarray(ref["pos"]).view(np.uint16))
+    frac, rmse, mean, mx = assert_radiance_close(ref["color"], got["color"], f"bench shape {scene}")
+    want = orclib.filter_passes(got["color"], got["normal"], got["pos"], iters)[-1].view(np.uint16)
+    d = half_ulp_diff(want, got["filtered"].view(np.uint16))
+    # (five passes end to end: a one-step difference of an early pass — exp is approximated differently — can grow to
+    # two on a noisy frame; pass by pass, above, the bar is one step)
+    assert d.max() <= 2 and (d == 0).mean() > 0.995, (int(d.max()), float((d == 0).mean()))
+    # --- counters: the traversals executed = the oracle's per-sample traversals minus the primary rays a batch shares
+    shared = (spp - 1) * frames
+    want_rays = int(ref["stats_sum"][..., 0].sum()) - shared * W * H
+    want_visits = int(ref["stats_sum"][..., 1].sum()) - shared * int(ref["visits"].sum())
+    assert cnt.paths == W * H * spp * frames
+    assert abs(int(cnt.rays) - want_rays) <= 0.002 * want_rays, (cnt.rays, want_rays)
+    assert abs(int(cnt.node_visits) - want_visits) <= 0.005 * want_visits, (cnt.node_visits, want_visits)
+    print(f"bench shape {scene}: {frames} frames, lanes {[s['lane'] for s in schedules]}, rows masks "
+          f"{[s['rows_stage_mask'] for s in schedules]}, outliers {frac:.2e}, RMSE {rmse:.3e} (mean {mean:.3f}), "
+          f"filter exact {float((d == 0).mean()):.5f}, rows rays {cnt.rows_rays} of {cnt.rays}")
+
+
+def test_bench_shape_metric_frame_against_oracle():
+    """BASELINE.json configs[2] exactly as bench.py times it: scene.obj 1920x1080, 4 spp, maxBounces 5, 5 filter passes."""
+    bench_shape("scene", 6, want_dense=False)
+
+
+def test_bench_shape_dense_frame_against_oracle():
+    """cases.room: every pixel sees geometry -> stages of millions of rays -> three extend blocks per CU, no row mode."""
+    bench_shape("room", 5, want_dense=True)
