@@ -30,7 +30,7 @@ HOST_HDRS := $(wildcard $(HOSTDIR)/*.hpp) $(wildcard $(ROOT)/include/*.h)
 HIP_SRCS  := $(wildcard $(CSRC)/*.hip)
 HIP_HDRS  := $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) $(wildcard $(ROOT)/include/*.h)
 
-.PHONY: all host hip oracle ref clean headless
+.PHONY: all host hip oracle ref clean headless debugwalk
 all: host hip oracle headless
 
 host: $(LIBDIR)/librt_host.so
@@ -45,9 +45,22 @@ $(LIBDIR)/librt_host.so: $(HOST_SRCS) $(HOST_HDRS)
 $(LIBDIR)/rt_headless: $(HOSTDIR)/main.cpp $(LIBDIR)/librt_host.so
 	$(CXX) $(HOSTFLAGS) -o $@ $(HOSTDIR)/main.cpp -L$(LIBDIR) -lrt_host -Wl,-rpath,'$$ORIGIN' -ldl -lpthread
 
-$(LIBDIR)/librt_hip.so: $(HIP_SRCS) $(HIP_HDRS)
+# one object per translation unit (build/ is not tracked), so that an edit recompiles only its own file
+OBJDIR   := $(ROOT)/build
+HIP_OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(HIP_SRCS))
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(LIBDIR)/librt_hip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRCS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(HIP_OBJS)
+
+# Development build: every link / leaf range a walk follows is checked inside the kernels (trace3_device.h: RT_WALK_CHECK);
+# run the GPU tests on it with RT_HIP_LIB=$(LIBDIR)/variants/librt_hip_debugwalk.so (tests/conftest.py reads the counters).
+debugwalk: $(LIBDIR)/variants/librt_hip_debugwalk.so
+$(LIBDIR)/variants/librt_hip_debugwalk.so: $(HIP_SRCS) $(HIP_HDRS)
+	@mkdir -p $(LIBDIR)/variants
+	$(HIPCC) $(HIPFLAGS) -DRT_DEBUG_WALK -shared -o $@ $(HIP_SRCS)
 
 $(ROOT)/oracle/librt_oracle.so: $(ROOT)/oracle/rt_oracle.c $(ROOT)/oracle/rt_oracle.h
 	$(CC) $(ORCFLAGS) -shared -o $@ $(ROOT)/oracle/rt_oracle.c -lm
@@ -58,4 +71,4 @@ ref:
 
 clean:
 	rm -f $(LIBDIR)/*.so $(LIBDIR)/rt_headless $(ROOT)/oracle/librt_oracle.so
-	rm -rf $(ROOT)/oracle/_ref
+	rm -rf $(ROOT)/oracle/_ref $(OBJDIR)

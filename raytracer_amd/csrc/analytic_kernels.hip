@@ -12,6 +12,7 @@
 // pixel are traced by one launch with the running colour kept in registers: sample k is blended as the
 // reference blends dispatch k (mix(new, old, blendFactor_k)), so the image is read and written once per batch
 // instead of once per sample and the result is bit-identical to k launches.
+#define RT_DEBUG_WALK_EXPORT rt_debug_walk_violations_analytic
 #include "trace3_device.h"
 
 #include "analytic.h"

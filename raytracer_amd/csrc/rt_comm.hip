@@ -35,11 +35,19 @@ const RcclApi &rccl() {
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
+        // Only dlsym'd pointers are used, so the library is opened RTLD_LOCAL: its nccl* symbols must not become visible to
+        // libraries loaded later (a PyTorch imported AFTER this call binds its own bundled RCCL / HIP runtime; with
+        // RTLD_GLOBAL it resolved nccl* against this copy and the process aborted at exit with a double free).
+        // A copy the process already holds is used as it is (RTLD_NOLOAD probe: PyTorch's, when it was imported first),
+        // so that one process runs one RCCL.
         void *lib = nullptr;
-        // by soname first: a process that already holds an RCCL (PyTorch bundles one) keeps using that one copy
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (lib) break;
+        }
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (lib) break;
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!lib) {
             api.why = std::string("cannot open librccl.so.1: ") + dlerror();

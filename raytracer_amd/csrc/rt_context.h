@@ -67,6 +67,7 @@ struct rt_ctx {
         DevBuf stageNormal, stagePos;   // the frame's G-buffer until its last kernel commits it
         size_t wfCapacity = 0, wfRadianceSlots = 0;
         hipEvent_t tick = nullptr;      // recorded on the lane's stream when the other lane (or a join) needs to wait for it
+        bool dirty = false;             // the launcher moved on to another lane while this one held work not yet joined
     } lane[RT_MAX_LANES];
     int laneNow = 0;                    // lane of the stream that `stream` currently is (when it is one of ours)
     int lanesAvailable = 1;             // lanes whose stream and event could be created

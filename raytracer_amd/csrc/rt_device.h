@@ -57,7 +57,7 @@ struct RtScene {
     const RtMtl *mtls;
     const RtTri128 *emitters;
     int numNodes, numTris, numMtls, numEmitters;
-    // Nodes [0, cacheNodes) are read from the block's LDS copy (trace3_device.h: fillNodeCache / loadNode); set per
+    // Nodes [0, cacheNodes) are read from the block's LDS copy (trace3_device.h: fillNodeCache / loadNodeT); set per
     // launch by the launcher of a kernel that fills the cache, 0 otherwise.  Nodes are numbered breadth-first
     // (reference BVH.cpp:223-241), so a prefix of the node array is exactly the top levels every ray walks.
     int cacheNodes;

@@ -133,9 +133,12 @@ void spanStop(rt_ctx *c, TimedSpan &s, hipStream_t stream = nullptr) {
 // every entry point that reads or writes what a frame reads or writes, except the pipelined trace and the filter.
 int rtJoinLanes(rt_ctx *c) {
     for (rt_ctx::Lane &L : c->lane) {
-        if (!L.stream || L.stream == c->stream || !L.tick) continue;
+        // (a lane that was never left with work on it — every lane of a context that has not had frames in flight —
+        // needs no event: the call then touches no stream but the current one, e.g. a caller's stream under capture)
+        if (!L.stream || L.stream == c->stream || !L.tick || !L.dirty) continue;
         HIP_TRY(c, hipEventRecord(L.tick, L.stream));
         HIP_TRY(c, hipStreamWaitEvent(c->stream, L.tick, 0));
+        L.dirty = false; // what it held is ordered before everything queued on the current stream from now on
     }
     return RT_OK;
 }
@@ -368,8 +371,10 @@ int rt_set_stream(rt_ctx *c, void *hip_stream) {
     int r = bind(c);
     if (r) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (rt_ctx::Lane &L : c->lane)
+    for (rt_ctx::Lane &L : c->lane) {
         if (L.stream) HIP_TRY(c, hipStreamSynchronize(L.stream));
+        L.dirty = false; // (drained: nothing left to join)
+    }
     c->chainValid = false;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
     c->laneNow = 0;
@@ -560,8 +565,10 @@ int rt_resize(rt_ctx *c, int width, int height) {
     int r = bind(c);
     if (r) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (rt_ctx::Lane &L : c->lane)
+    for (rt_ctx::Lane &L : c->lane) {
         if (L.stream) HIP_TRY(c, hipStreamSynchronize(L.stream));
+        L.dirty = false;
+    }
     rtCommQuiesce(c);
     if (width != c->width || height != c->height) c->assembledPixelBytes = 0; // the assembled frame belongs to the old size
     const size_t n = (size_t)width * height;
@@ -766,7 +773,9 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     // the previous frame's queue sizes, if they have arrived and belong to the same kind of frame
     const long long key = ((long long)(r.x1 - r.x0) << 40) ^ ((long long)(r.y1 - r.y0) << 20) ^ ((long long)r.x0 << 10) ^
                           (long long)r.y0 ^ ((long long)n << 56) ^ ((long long)p->maxBounces << 60) ^ ((long long)p->flags << 32);
-    if (c->countsPending && hipEventQuery(c->countsEvent) == hipSuccess) {
+    // (the no-allocation entry point neither queries nor records events and copies nothing to the host: only memsets
+    // and kernel launches on the current stream, so that it can also run under stream capture)
+    if (!noAlloc && c->countsPending && hipEventQuery(c->countsEvent) == hipSuccess) {
         std::memcpy(c->predictedCounts, c->hostCounts, sizeof c->predictedCounts);
         c->countsPending = false;
         c->havePrediction = true;
@@ -799,7 +808,7 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         si.flat_record = wf.flat.flag ? 1 : 0;
         si.static_scratch = noAlloc ? 1 : 0;
     }
-    if (e == hipSuccess && !c->countsPending) { // (one read-back in flight at a time: hostCounts is a single buffer)
+    if (e == hipSuccess && !noAlloc && !c->countsPending) { // (one read-back in flight at a time: hostCounts is a single buffer)
         if (hipMemcpyAsync(c->hostCounts, wf.counts, 32 * sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
             hipEventRecord(c->countsEvent, c->stream) == hipSuccess) {
             // (frames are queued faster than they finish: the newest sizes that HAVE arrived stay in use meanwhile)
@@ -886,6 +895,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             rt_ctx::Lane &prev = c->lane[c->laneNow];
             HIP_TRY(c, hipEventRecord(prev.tick, c->stream));
             before = prev.tick;
+            prev.dirty = true; // left with work on it: later joins must wait for it
             c->laneNow = (c->laneNow + 1) % lanes;
             c->stream = c->lane[c->laneNow].stream;
             c->chainValid = false;
@@ -1050,7 +1060,7 @@ int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const
     if (tilePixels == 0) return RT_OK;
     int rc = bind(c);
     if (rc) return rc;
-    if ((rc = rtJoinLanes(c))) return rc; // (two event calls on events made at rt_create: nothing is allocated)
+    if ((rc = rtJoinLanes(c))) return rc; // (event calls on events made at rt_create, and only if frames were in flight: nothing is allocated)
     unsigned char *base = c->device < RT_MAX_DEVICES ? (unsigned char *)rtStaticScratchPtr[c->device] : nullptr;
     if (!base) return fail(c, RT_ESTATE, "rt_trace_batch_static: the static scratch array was not resolved on this device");
     RtScene sc;
@@ -1351,8 +1361,10 @@ int rt_sync(rt_ctx *c) {
     int rc = bind(c);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    for (rt_ctx::Lane &L : c->lane)
+    for (rt_ctx::Lane &L : c->lane) {
         if (L.stream) HIP_TRY(c, hipStreamSynchronize(L.stream));
+        L.dirty = false;
+    }
     rtCommQuiesce(c);
     return RT_OK;
 }

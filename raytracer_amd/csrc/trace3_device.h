@@ -318,39 +318,32 @@ __device__ __forceinline__ void fillNodeCache(const RtScene &sc) {
 struct NodeLinks {
     int hitNext, missNext, leafFirst, leafCount; // leafCount = 0 for an inner node
 };
-__device__ __forceinline__ void loadNode(const RtScene &sc, int node, float4 &b0, float4 &b1, NodeLinks &k) {
-    if (node < sc.cacheNodes) {
-        b0 = rtLdsNodes[2 * node];
-        b1 = rtLdsNodes[2 * node + 1];
-    } else {
-        b0 = sc.boxes[2 * node];
-        b1 = sc.boxes[2 * node + 1];
-    }
-    const int w0 = __float_as_int(b0.w), w1 = __float_as_int(b1.w);
-    if (sc.packedLeaves) {
-        const bool leaf = w1 < 0;
-        k.missNext = w0;
-        k.hitNext = leaf ? w0 : w1;
-        k.leafFirst = w1 & 0x03FFFFFF;
-        k.leafCount = leaf ? ((w1 >> 26) & 31) + 1 : 0;
-    } else {
-        const int2 lr = sc.leaves[node];
-        k.hitNext = w0;
-        k.missNext = w1;
-        k.leafFirst = lr.x;
-        k.leafCount = lr.y;
-    }
-}
 
-// The same fetch with the case decided at compile time, for the kernel whose walk is one long chain of dependent
-// steps (the wavefront extend kernel): NODES_PACKED_LDS = packed records, the whole node array in LDS (the named
-// scenes); NODES_PACKED = packed records, a prefix in LDS; NODES_ANY = whatever the scene has.  A step of the general
-// form spends more cycles in its branches than in the box test.
-enum { NODES_ANY = 0, NODES_PACKED = 1, NODES_PACKED_LDS = 2 };
+// The node fetch of a walk is decided where the kernel is LAUNCHED, once, for the scene as uploaded (rtNodeFetchFor
+// below), and is a template argument of every kernel that walks the tree:
+//   NODES_PLAIN       plain records (w0 = hitNext, w1 = missNext, leaf range from sc.leaves), read from memory:
+//                     trees the packed form cannot hold (a leaf of more than 32 triangles, an inner node whose hit link
+//                     ends the walk, leaves whose two links differ)
+//   NODES_PACKED      packed records (rt_device.h), the first sc.cacheNodes of them in LDS
+//   NODES_PACKED_LDS  packed records, the whole node array in LDS (the named scenes)
+// There is deliberately NO run-time test of sc.packedLeaves on the walk.  A step of a run-time form spent more cycles
+// in its branches than in the box test — and, found in round 3 (profiles/r03_uniform_test_in_divergent_loop.txt): a
+// uniform test evaluated inside the divergent walk loop of one inlined traverse() was re-used by the compiler in the
+// next inlined traverse() as a lane mask computed under the first loop's exec mask, so that waves whose active lanes
+// had all left the first loop early took the WRONG side of the uniform test.  With a run-time "packed or plain" test
+// that means a plain record decoded as packed: missNext = -1 reads as a leaf of 32 triangles at index 67 108 863, a read
+// 3 GB past the triangle stream — the GPU memory fault of round 2's withdrawn traverse() edit.
+enum { NODES_PLAIN = 0, NODES_PACKED = 1, NODES_PACKED_LDS = 2 };
 template <int MODE>
 __device__ __forceinline__ void loadNodeT(const RtScene &sc, int node, float4 &b0, float4 &b1, NodeLinks &k) {
-    if (MODE == NODES_ANY) {
-        loadNode(sc, node, b0, b1, k);
+    if (MODE == NODES_PLAIN) {
+        b0 = sc.boxes[2 * node];
+        b1 = sc.boxes[2 * node + 1];
+        const int2 lr = sc.leaves[node];
+        k.hitNext = __float_as_int(b0.w);
+        k.missNext = __float_as_int(b1.w);
+        k.leafFirst = lr.x;
+        k.leafCount = lr.y;
         return;
     }
     if (MODE == NODES_PACKED_LDS || node < sc.cacheNodes) {
@@ -369,9 +362,25 @@ __device__ __forceinline__ void loadNodeT(const RtScene &sc, int node, float4 &b
 }
 
 // ---------------------------------------------------------------- traversal
+#ifdef RT_DEBUG_WALK
+// Development build (make hip EXTRA_HIPFLAGS=-DRT_DEBUG_WALK): every link followed and every leaf range entered by
+// traverse() is checked against the scene's sizes inside the kernel; a violation is counted here, and the walk ends
+// instead of reading out of bounds.  rt_debug_walk_violations (rt_launcher.hip) reads the counters.
+__device__ int rtWalkViolations[4]; // [0] link out of range, [1] leaf range beyond the triangle stream, [2] packed loop on an unpacked scene
+// (no do { } while (0) wrapper: onFail may `break` out of the enclosing walk loop)
+#define RT_WALK_CHECK(cond, slot, onFail)          \
+    if (!(cond)) {                                 \
+        atomicAdd(&rtWalkViolations[slot], 1);     \
+                onFail;                                    \
+    }
+#else
+#define RT_WALK_CHECK(cond, slot, onFail)
+#endif
+
 // intersectGeometry's loop (trace3.cs:226-269) + intersectTriangles (:172-186).
 // Returns false when the MAX_FOLLOWS abort was taken (trace3.cs:228-234).
-template <int NODES = NODES_ANY, bool WATERTIGHT = false>
+// NODES: see loadNodeT above; chosen at launch, never tested at run time.
+template <int NODES = NODES_PLAIN, bool WATERTIGHT = false>
 __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origin, f3 dir, f3 invdir, Hit &hit) {
     // "while-while" form: every lane first walks nodes until it holds a leaf whose box it entered
     // (or runs out of nodes), then the wave tests leaf triangles together.  Per lane the sequence of
@@ -387,34 +396,78 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
     const bool ltx = invdir.x < 0.0f, lty = invdir.y < 0.0f, ltz = invdir.z < 0.0f;
     for (;;) {
         int leafFirst = 0, leafCount = 0;
-        while (next != -1 && leafCount == 0) {
-            iterations++;
-            if (iterations > c.maxFollows) { // trace3.cs:228-234
+        if constexpr (NODES == NODES_PLAIN) {
+            while (next != -1 && leafCount == 0) {
+                iterations++;
+                if (iterations > c.maxFollows) { // trace3.cs:228-234
+                    ok = false;
+                    hit.tridx = -1;
+                    next = -1;
+                    break;
+                }
+                RT_WALK_CHECK((unsigned)next < (unsigned)sc.numNodes, 0, { next = -1; break; });
+                float4 b0, b1;
+                NodeLinks k;
+                loadNodeT<NODES_PLAIN>(sc, next, b0, b1, k);
+                // intersectBox, geometry.glsl:66-76
+                const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
+                            m1z = (b0.z - origin.z) * invdir.z;
+                const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
+                            m2z = (b1.z - origin.z) * invdir.z;
+                const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
+                const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
+                const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f;
+                if (!boxHit || mint > nearest) {
+                    next = k.missNext;
+                } else {
+                    leafFirst = k.leafFirst;
+                    leafCount = k.leafCount; // 0 for inner nodes: keep walking
+                    next = k.hitNext;
+                }
+            }
+        } else {
+            // Packed records, the loop of the wavefront extend kernel (wavefront.hip) written for instruction count: the
+            // leaf a lane enters is kept as the record's raw word and decoded after the loop, `next` is one conditional
+            // move, the MAX_FOLLOWS abort is taken after the loop by the lanes the limit stopped (they count the visit the
+            // reference's loop starts and abandons).  Same visits, same tests, same order.
+            static_assert(NODES == NODES_PACKED || NODES == NODES_PACKED_LDS, "packed walk: packed node records only");
+            RT_WALK_CHECK(__builtin_amdgcn_readfirstlane(sc.packedLeaves) != 0, 2, { next = -1; });
+            int leafWord = 0; // w1 of the leaf entered (negative), 0: none yet
+            while (next != -1 && leafWord == 0 && iterations < c.maxFollows) {
+                iterations++;
+                RT_WALK_CHECK((unsigned)next < (unsigned)sc.numNodes, 0, { next = -1; break; });
+                float4 b0, b1;
+                if (NODES == NODES_PACKED_LDS || next < sc.cacheNodes) {
+                    b0 = rtLdsNodes[2 * next];
+                    b1 = rtLdsNodes[2 * next + 1];
+                } else {
+                    b0 = sc.boxes[2 * next];
+                    b1 = sc.boxes[2 * next + 1];
+                }
+                const int w0 = __float_as_int(b0.w), w1 = __float_as_int(b1.w);
+                const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
+                            m1z = (b0.z - origin.z) * invdir.z;
+                const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
+                            m2z = (b1.z - origin.z) * invdir.z;
+                const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
+                const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
+                const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f; // geometry.glsl:66-76
+                const bool enter = boxHit && !(mint > nearest);
+                const bool leaf = w1 < 0;
+                next = (enter && !leaf) ? w1 : w0; // (a leaf's hitNext equals its missNext)
+                leafWord = (enter && leaf) ? w1 : 0;
+            }
+            if (next != -1 && leafWord == 0 && iterations >= c.maxFollows) { // trace3.cs:228-234
+                iterations++; // the visit that the reference's loop starts and abandons
                 ok = false;
                 hit.tridx = -1;
                 next = -1;
-                break;
             }
-            float4 b0, b1;
-            NodeLinks k;
-            loadNodeT<NODES>(sc, next, b0, b1, k);
-            // intersectBox, geometry.glsl:66-76
-            const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
-                        m1z = (b0.z - origin.z) * invdir.z;
-            const float m2x = (b1.x - origin.x) * invdir.x, m2y = (b1.y - origin.y) * invdir.y,
-                        m2z = (b1.z - origin.z) * invdir.z;
-            const float mint = fmaxf(fmaxf(ltx ? m2x : m1x, lty ? m2y : m1y), ltz ? m2z : m1z);
-            const float maxt = fminf(fminf(ltx ? m1x : m2x, lty ? m1y : m2y), ltz ? m1z : m2z);
-            const bool boxHit = maxt >= 0.0f && mint <= maxt * 1.00000024f;
-            if (!boxHit || mint > nearest) {
-                next = k.missNext;
-            } else {
-                leafFirst = k.leafFirst;
-                leafCount = k.leafCount; // 0 for inner nodes: keep walking
-                next = k.hitNext;
-            }
+            leafFirst = leafWord & 0x03FFFFFF;
+            leafCount = leafWord != 0 ? ((leafWord >> 26) & 31) + 1 : 0;
         }
         if (leafCount <= 0) break;
+        RT_WALK_CHECK(leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numTris, 1, { next = -1; break; });
         if (WATERTIGHT)
             testLeafWt(sc.tris128, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
         else
@@ -428,6 +481,12 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
     return ok;
 }
 
+// The node fetch a kernel that calls traverse() is launched with, for the scene as uploaded (cacheNodes: the nodes
+// the launch copies to LDS).  The ONLY place that may choose a packed form.
+inline int rtNodeFetchFor(const RtScene &sc, int cacheNodes) {
+    return !sc.packedLeaves ? NODES_PLAIN : cacheNodes >= sc.numNodes ? NODES_PACKED_LDS : NODES_PACKED;
+}
+
 __device__ __forceinline__ const RtTri128 *triPtr(const RtScene &sc, int i) {
     return (unsigned)i < (unsigned)sc.numTris ? sc.tris128 + i : nullptr;
 }
@@ -438,11 +497,11 @@ __device__ __forceinline__ RtMtl fetchMtl(const RtScene &sc, int i) {
 }
 
 // intersectGeometry's epilogue (trace3.cs:259-276): attributes of the closest hit
-template <bool WATERTIGHT = false>
+template <bool WATERTIGHT = false, int NODES = NODES_PLAIN>
 __device__ __forceinline__ void intersectGeometry(const RtScene &sc, PathCtx &c, f3 origin, f3 dir, f3 invdir,
                                                   Surface &SI) {
     Hit h;
-    traverse<NODES_ANY, WATERTIGHT>(sc, c, origin, dir, invdir, h);
+    traverse<NODES, WATERTIGHT>(sc, c, origin, dir, invdir, h);
     SI.tridx = h.tridx;
     SI.normal = F3(0, 0, 0);
     SI.point = F3(0, 0, 0);
@@ -487,10 +546,10 @@ __device__ __forceinline__ bool sameTriangle(const RtScene &sc, int tridx, const
 }
 
 // visible(), trace3.cs:487-497
-template <bool WATERTIGHT = false>
+template <bool WATERTIGHT = false, int NODES = NODES_PLAIN>
 __device__ __forceinline__ bool visible(const RtScene &sc, PathCtx &c, f3 origin, f3 wi, const LightTri &t) {
     Hit h;
-    traverse<NODES_ANY, WATERTIGHT>(sc, c, origin, wi, rcp3(wi), h);
+    traverse<NODES, WATERTIGHT>(sc, c, origin, wi, rcp3(wi), h);
     return sameTriangle(sc, h.tridx, t);
 }
 
@@ -651,5 +710,19 @@ __device__ __forceinline__ void waveAdd(unsigned long long *dst, unsigned v) {
 }
 
 } // namespace
+
+#ifdef RT_DEBUG_WALK
+#ifndef RT_DEBUG_WALK_EXPORT
+#error "RT_DEBUG_WALK: define RT_DEBUG_WALK_EXPORT (the name of this translation unit's read-out function) before including trace3_device.h"
+#endif
+// reads (and clears) this translation unit's violation counters: blocking
+extern "C" int RT_DEBUG_WALK_EXPORT(int *out4) {
+    const int zero[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(rtWalkViolations), 16);
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(rtWalkViolations), zero, 16);
+    return (int)e;
+}
+#endif
+
 
 #endif

@@ -18,9 +18,10 @@
 //    triangles as three aligned 16-B loads of {v0, e1, e2};
 //  * counters (rays / node visits / triangle tests) are summed across the wave with DPP
 //    reductions and issued as one atomic per wave and counter.
+#define RT_DEBUG_WALK_EXPORT rt_debug_walk_violations_per_pixel
 #include "trace3_device.h"
 
-template <bool WATERTIGHT>
+template <bool WATERTIGHT, int NODES>
 __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img, rt_trace_params p, rt_rect tile,
                                                         int tilesX, int tilesY, int xcdRemap,
                                                         RtCountersDev *counters) {
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
     c.rays = c.visits = c.tests = c.shaded = 0;
     c.lastIterations = 0;
     unsigned primaryVisits = 0, primaryTests = 0;
-    fillNodeCache(sc); // the top of the tree (all of it for the named scenes) in LDS: trace3_device.h, loadNode
+    fillNodeCache(sc); // the top of the tree (all of it for the named scenes) in LDS: trace3_device.h, loadNodeT
 
     if (active) {
         const int W = img.width, H = img.height;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
         const size_t pix = (size_t)y * W + x;
         for (int bounces = 0;; ++bounces) {
             Surface SI;
-            intersectGeometry<WATERTIGHT>(sc, c, origin, dir, invdir, SI);
+            intersectGeometry<WATERTIGHT, NODES>(sc, c, origin, dir, invdir, SI);
             const bool found = SI.tridx != -1;
             RtMtl m = fetchMtl(sc, SI.matidx);
             if (found) {
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
             const LightTri light = loadLight(sc, li);
             DirectTerms T;
             estimateDirectPrepare(c, origin, dir, SI.normal, m, bounces, light, T);
-            const bool vis1 = visible<WATERTIGHT>(sc, c, origin, T.wi1, light);
-            const bool vis2 = visible<WATERTIGHT>(sc, c, origin, T.wi2, light);
+            const bool vis1 = visible<WATERTIGHT, NODES>(sc, c, origin, T.wi1, light);
+            const bool vis2 = visible<WATERTIGHT, NODES>(sc, c, origin, T.wi2, light);
             const f3 Ke30 = ld3(fetchMtl(sc, light.mtlIndex).Ke) * 30.0f;
             const f3 Ld = estimateDirectResolve(T.f1, T.w1, T.lp1, T.cond1, T.f2, T.w2, T.bp2, T.cond2, Ke30, vis1, vis2) /
                           light_prob;
@@ -142,9 +143,14 @@ hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace
     const int tilesX = (tw + 15) / 16, tilesY = (th + 15) / 16;
     const int ntiles = tilesX * tilesY;
     const int nblocks = ((ntiles + 7) / 8) * 8; // multiple of 8 so that the XCD re-map is a bijection
-    auto kernel = (p.flags & RT_FLAG_WATERTIGHT) ? rt_trace3_kernel<true> : rt_trace3_kernel<false>;
     RtScene cached = sc;
     cached.cacheNodes = sc.packedLeaves ? (sc.numNodes < 896 ? sc.numNodes : 896) : 0;
+    // the walk's node fetch, decided here for the scene as uploaded (trace3_device.h: traverse)
+    const bool wt = (p.flags & RT_FLAG_WATERTIGHT) != 0;
+    const int nodes = rtNodeFetchFor(cached, cached.cacheNodes);
+    auto kernel = nodes == NODES_PLAIN ? (wt ? rt_trace3_kernel<true, NODES_PLAIN> : rt_trace3_kernel<false, NODES_PLAIN>)
+                  : nodes == NODES_PACKED_LDS ? (wt ? rt_trace3_kernel<true, NODES_PACKED_LDS> : rt_trace3_kernel<false, NODES_PACKED_LDS>)
+                                              : (wt ? rt_trace3_kernel<true, NODES_PACKED> : rt_trace3_kernel<false, NODES_PACKED>);
     hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(256), (size_t)cached.cacheNodes * 32, stream, cached, img, p, tile, tilesX,
                        tilesY, xcdRemap, counters);
     return hipGetLastError();

@@ -25,6 +25,7 @@
 // what is left is the latency of the scan's loads from L2 (waves spend 91 % of their cycles in s_waitcnt).
 // Staging the cells of all objects in LDS (48 KB for room.obj) was measured twice and is slower than reading
 // them through L1 (440 vs 295 ms before, 198 vs 150 ms after the other changes), so it is not done.
+#define RT_DEBUG_WALK_EXPORT rt_debug_walk_violations_rl
 #include "trace3_device.h"
 
 #include "trace3_rl.h"
@@ -338,6 +339,7 @@ __device__ __forceinline__ f3 sampleScatteringDir(const RtScene &sc, const RtQTa
     return normalize((uvec * d.x + vvec * d.y) + nvec * d.z);
 }
 
+template <int NODES>
 __global__ __launch_bounds__(256) void rt_trace3_rl_kernel(RtScene sc, RtQTable q, RtImages img, rt_trace_params p,
                                                            rt_rect tile, int tilesX, int mode, RtCountersDev *counters) {
     const __amdgpu_buffer_rsrc_t rows = __builtin_amdgcn_make_buffer_rsrc(q.qt, 0, q.numQ <= 0x1FFFFFFF ? q.numQ * 4 : 0, 0x00020000);
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void rt_trace3_rl_kernel(RtScene sc, RtQTable 
     c.rays = c.visits = c.tests = c.shaded = 0;
     c.lastIterations = 0;
     unsigned updates = 0, primaryVisits = 0, primaryTests = 0;
-    fillNodeCache(sc); // the top of the tree (all of it for the named scenes) in LDS: trace3_device.h, loadNode
+    fillNodeCache(sc); // the top of the tree (all of it for the named scenes) in LDS: trace3_device.h, loadNodeT
 
     if (active) {
         const int W = img.width, H = img.height;
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(256) void rt_trace3_rl_kernel(RtScene sc, RtQTable 
         prevSI.tridx = -1; prevSI.matidx = 0; prevSI.normal = prevSI.point = F3(0, 0, 0);
         for (int bounces = 0;; ++bounces) {
             Surface SI;
-            intersectGeometry(sc, c, origin, dir, invdir, SI);
+            intersectGeometry<false, NODES>(sc, c, origin, dir, invdir, SI);
             const bool found = SI.tridx != -1;
             bool isAreaLight = false;
             const RtMtl m = fetchMtl(sc, SI.matidx);
@@ -473,7 +475,10 @@ hipError_t rtLaunchTrace3RL(const RtScene &sc, const RtQTable &q, const RtImages
     }();
     RtScene cached = sc;
     cached.cacheNodes = sc.packedLeaves ? (sc.numNodes < 896 ? sc.numNodes : 896) : 0;
-    hipLaunchKernelGGL(rt_trace3_rl_kernel, dim3(tilesX * tilesY), dim3(256), (size_t)cached.cacheNodes * 32, stream, cached, q,
+    const int nodes = rtNodeFetchFor(cached, cached.cacheNodes); // the walk's node fetch (trace3_device.h: traverse)
+    auto kernel = nodes == NODES_PLAIN ? rt_trace3_rl_kernel<NODES_PLAIN>
+                  : nodes == NODES_PACKED_LDS ? rt_trace3_rl_kernel<NODES_PACKED_LDS> : rt_trace3_rl_kernel<NODES_PACKED>;
+    hipLaunchKernelGGL(kernel, dim3(tilesX * tilesY), dim3(256), (size_t)cached.cacheNodes * 32, stream, cached, q,
                        img, p, tile, tilesX, mode, counters);
     return hipGetLastError();
 }

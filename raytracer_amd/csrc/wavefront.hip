@@ -27,6 +27,7 @@
 // Path state lives in HBM as structure-of-arrays of 16-byte records (coalesced 16 B per lane).
 // Results are identical to the per-pixel kernel's for every pixel (same operations in the same order
 // per path); only the order in which paths are processed differs.
+#define RT_DEBUG_WALK_EXPORT rt_debug_walk_violations_wavefront
 #include "trace3_device.h"
 #include "wavefront.h"
 
@@ -413,9 +414,9 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     int raysPerWave = 64;
     while (raysPerWave > max(p.extendMinRays, 1) && (long long)(raysPerWave / 2) * residentWaves * p.extendFill >= total) raysPerWave >>= 1;
     if (p.extendRaysPerWave > 0) raysPerWave = p.extendRaysPerWave;
-    if (!sc.packedLeaves) raysPerWave = 64; // the pair list below is sized for leaves of at most 32 triangles
+    if (NODES == NODES_PLAIN) raysPerWave = 64; // the pair list below is sized for leaves of at most 32 triangles
     // 0: every lane tests its own leaf; 1: the wave shares the tests out (phase 2 below); 2: decided round by round
-    const int coopMode = !sc.packedLeaves ? 0 : raysPerWave < 64 ? 1 : p.extendCoop;
+    const int coopMode = NODES == NODES_PLAIN ? 0 : raysPerWave < 64 ? 1 : p.extendCoop;
     const int walkStop = coopMode == 0 ? 8 : p.walkStop; // see phase 1
     const bool rayLane = lane < raysPerWave;
     fillNodeCache(sc);
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         // launcher times both, rt_launcher.hip).  Beyond the L2s every step is a trip to memory and stopping early
         // pays at any width (walkMin = 1).
         if (walkStop < 8 && walking >= p.walkMin) stopAt = max(1, (walking * walkStop) >> 3);
-        if constexpr (NODES == NODES_ANY) {
+        if constexpr (NODES == NODES_PLAIN) {
             while (active && next != -1 && leafCount == 0 && found < stopAt) {
                 iterations++;
                 if (iterations > p.maxFollows) { // trace3.cs:228-234
@@ -534,6 +535,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                     bounded = false; // an aborted walk proves nothing: reported as a miss, i.e. not visible
                     break;
                 }
+                RT_WALK_CHECK((unsigned)next < (unsigned)sc.numNodes, 0, { next = -1; break; });
                 float4 b0, b1;
                 NodeLinks k;
                 loadNodeT<NODES>(sc, next, b0, b1, k);
@@ -564,6 +566,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             __builtin_amdgcn_s_waitcnt(0x0070);
             while (active && next != -1 && leafWord == 0 && iterations < p.maxFollows && found < stopAt) {
                 iterations++;
+                RT_WALK_CHECK((unsigned)next < (unsigned)sc.numNodes, 0, { next = -1; break; });
                 float4 b0, b1;
                 if (NODES == NODES_PACKED_LDS || next < sc.cacheNodes) {
                     b0 = rtLdsNodes[2 * next];
@@ -600,6 +603,8 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             for (int o = 32; o; o >>= 1) d = max(d, __shfl_xor(d, o, 64));
             wtWalk += d;
         } const long long c2 = clock64(); wtWalkC += c2 - c1;)
+        RT_WALK_CHECK(!(active && leafCount > 0) || (leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numTris), 1,
+                      { leafCount = 0; next = -1; });
         // phase 2: the leaves' triangles (geometry.glsl:31-51, trace3.cs:172-186), shared out over the wave.
         // Lanes hold leaves of 1..32 triangles (or none); testing "my leaf" lane by lane leaves most lanes idle
         // (measured: 38 % of the lanes active on room.obj, 20 % on scene.obj, and the kernel is VALU-issue
@@ -960,6 +965,8 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
 
         // ---- leaf: 16 triangles per step across the row, closest accepted hit by row reduction
         WT(const long long c2 = clock64(); wtWalkC += c2 - c1; wtLeaves += __any(active && leafCount > 0) ? 1 : 0;)
+        RT_WALK_CHECK(!(active && leafCount > 0) || (leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numTris), 1,
+                      { leafCount = 0; next = -1; });
         if (active && leafCount > 0) {
             const int i0 = leafFirst + rowLane, i1 = i0 + 16;
             const bool has0 = rowLane < leafCount, has1 = rowLane + 16 < leafCount;
@@ -1159,8 +1166,8 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
     const int logicBlocks = 256 * 4;
     // the walk's node fetch is chosen here, once per launch (trace3_device.h: loadNodeT)
-    const int extendNodes = !sc.packedLeaves ? NODES_ANY : scExtend.cacheNodes >= sc.numNodes ? NODES_PACKED_LDS : NODES_PACKED;
-    auto extendKernel = extendNodes == NODES_ANY ? (wt ? rt_wf_extend_kernel<NODES_ANY, true> : rt_wf_extend_kernel<NODES_ANY, false>)
+    const int extendNodes = !sc.packedLeaves ? NODES_PLAIN : scExtend.cacheNodes >= sc.numNodes ? NODES_PACKED_LDS : NODES_PACKED;
+    auto extendKernel = extendNodes == NODES_PLAIN ? (wt ? rt_wf_extend_kernel<NODES_PLAIN, true> : rt_wf_extend_kernel<NODES_PLAIN, false>)
                         : extendNodes == NODES_PACKED_LDS
                             ? (wt ? rt_wf_extend_kernel<NODES_PACKED_LDS, true> : rt_wf_extend_kernel<NODES_PACKED_LDS, false>)
                             : (wt ? rt_wf_extend_kernel<NODES_PACKED, true> : rt_wf_extend_kernel<NODES_PACKED, false>);
@@ -1180,7 +1187,7 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
         chosen->rowsStageMask = 0;
         chosen->dense = dense ? 1 : 0;
         chosen->extendBlocksPerCU = dense ? p.extendBlocksDense : p.extendBlocksPerCU;
-        chosen->nodeFetch = extendNodes == NODES_ANY ? 0 : extendNodes == NODES_PACKED ? 1 : 2;
+        chosen->nodeFetch = extendNodes == NODES_PLAIN ? 0 : extendNodes == NODES_PACKED ? 1 : 2;
     }
     auto extend = [&](int stage) {
         // rowMode 2: a stage that held few rays in the previous frame is bound by its longest walks, not by throughput

@@ -11,12 +11,16 @@
 // input that only resets frameNumber at frame K.  --gpus N renders on N GPUs of this node, one host thread and one
 // launcher context per GPU: the frame is split into screen-space tiles (tiling.hpp), every GPU traces its tile plus the
 // filter halo and filters it locally, rt_gather_tiles assembles the frame on GPU 0 over RCCL.
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <thread>
@@ -98,6 +102,7 @@ bool dumpFile(const std::string &path, const void *p, size_t n) {
 }
 
 struct Shared { // what the GPU threads read (built once) and where they report
+    explicit Shared(const Camera &c) : camera0(c) {}
     const Options *o;
     ModelLoader *loader;
     QTable *qt;
@@ -107,6 +112,21 @@ struct Shared { // what the GPU threads read (built once) and where they report
     unsigned char commId[RT_COMM_ID_BYTES];
     std::vector<int> status;
     std::vector<std::string> errors;
+    // One halo for the whole run: the largest any scripted frame filters with.  The tile grid depends on the halo
+    // (tiling.hpp: tileGrid) and SPACE / EQUAL / MINUS do not restart the accumulation (reference glfw_setter.cpp:
+    // 207-218), so a halo that grew with the filter settings would move the tiles — and blend freshly traced halo
+    // pixels onto colour that was never accumulated there — in the middle of a running average.
+    int halo = 0;
+    // a GPU thread that fails tells the others (checked once per frame) and main (which then exits non-zero even if
+    // a peer is stuck inside ncclCommInitRank / a collective waiting for the failed rank)
+    std::atomic<bool> abort{false};
+    std::atomic<int> finished{0};
+    std::mutex m;
+    std::condition_variable cv;
+};
+
+struct RankAborted : std::runtime_error {
+    RankAborted() : std::runtime_error("stopped: another GPU thread failed") {}
 };
 
 // The body of the reference's main() from the FrameBuffer on (main.cpp:32-134), on one GPU; with nranks > 1 for one
@@ -148,7 +168,8 @@ void renderOn(Shared &sh, int rank, int nranks) {
             filter.iterations = s.iterations;
             exposure = s.exposure;
             filtered = s.filterOn;
-            const int halo = filtered ? rttile::filterHalo(s.iterations) : 0;
+            if (sh.abort.load()) throw RankAborted();
+            const int halo = sh.halo;
             std::vector<rt_rect> rects((size_t)world);
             for (int r = 0; r < world; ++r) rects[(size_t)r] = rttile::tileRect(W, H, world, r, halo);
             if (tiled) {
@@ -164,8 +185,11 @@ void renderOn(Shared &sh, int rank, int nranks) {
             } else {
                 framebuffer.setTextureRead();
             }
+            // which image is gathered comes from this frame's scripted state, the same on every rank — not from
+            // FrameBuffer::readTexture, a process-wide static that the GPU threads write at their own pace
             if (tiled)
-                rtCheck(api.gather_tiles(ctx, (int)FrameBuffer::readTexture, rects.data(), world, 0), "rt_gather_tiles");
+                rtCheck(api.gather_tiles(ctx, filtered ? (int)RT_IMAGE_FILTERED : (int)RT_IMAGE_COLOR, rects.data(), world, 0),
+                        "rt_gather_tiles");
         }
         rtCheck(api.sync(ctx), "rt_sync");
 
@@ -203,10 +227,19 @@ void renderOn(Shared &sh, int rank, int nranks) {
         std::cout << line.str() << std::flush;
         rtReleaseCurrentContext();
         sh.status[(size_t)rank] = 0;
+    } catch (const RankAborted &e) {
+        sh.errors[(size_t)rank] = e.what();
+        sh.status[(size_t)rank] = 2;
     } catch (const std::exception &e) {
         sh.errors[(size_t)rank] = e.what();
         sh.status[(size_t)rank] = 1;
+        sh.abort.store(true);
     }
+    {
+        std::lock_guard<std::mutex> lock(sh.m);
+        sh.finished.fetch_add(1);
+    }
+    sh.cv.notify_all();
 }
 
 } // namespace
@@ -281,28 +314,50 @@ int main(int argc, char **argv) {
             lookAt = (lo + hi) * 0.5f;
             eye = lookAt + rtm::vec3(0.3f, 0.4f, 1.0f) * (1.5f * diag);
         }
-        Shared sh{&o, &loader, &qt, &bvh,
-                  Camera(eye, lookAt, rtm::vec3(0.0f, 1.0f, 0.0f), 60.0f, (float)o.width, (float)o.height, 1.0f, 2.0f),
-                  {}, {}, {}, {}};
+        Shared sh(Camera(eye, lookAt, rtm::vec3(0.0f, 1.0f, 0.0f), 60.0f, (float)o.width, (float)o.height, 1.0f, 2.0f));
+        sh.o = &o;
+        sh.loader = &loader;
+        sh.qt = &qt;
+        sh.bvh = &bvh;
         if (!scriptStates(o, sh.camera0, sh.states)) return -1;
+        for (const FrameState &s : sh.states)
+            if (s.filterOn) sh.halo = std::max(sh.halo, rttile::filterHalo(s.iterations));
         const int threads = std::max(o.gpus, 1);
         sh.status.assign((size_t)threads, 1);
         sh.errors.assign((size_t)threads, std::string());
+        auto report = [&]() {
+            int rc = 0;
+            for (int r = 0; r < threads; ++r)
+                if (sh.status[(size_t)r]) {
+                    std::cerr << "gpu " << r << ": " << (sh.errors[(size_t)r].empty() ? "did not finish" : sh.errors[(size_t)r]) << std::endl;
+                    rc = 1;
+                }
+            return rc;
+        };
         if (o.gpus > 0) {
             rtCheck(rtApi().comm_unique_id(sh.commId, RT_COMM_ID_BYTES), "rt_comm_unique_id");
             std::vector<std::thread> pool;
             for (int r = 0; r < o.gpus; ++r) pool.emplace_back(renderOn, std::ref(sh), r, o.gpus);
+            {
+                // all done, or one failed: then the others get ten seconds to notice (they check once per frame); a thread
+                // stuck in a collective that waits for the failed rank never will, so the process exits without it
+                std::unique_lock<std::mutex> lock(sh.m);
+                sh.cv.wait(lock, [&] { return sh.finished.load() == o.gpus || sh.abort.load(); });
+                if (sh.finished.load() != o.gpus)
+                    sh.cv.wait_for(lock, std::chrono::seconds(10), [&] { return sh.finished.load() == o.gpus; });
+            }
+            if (sh.finished.load() != o.gpus) {
+                report();
+                std::cerr << "rt_headless: a GPU thread failed and " << (o.gpus - sh.finished.load())
+                          << " other(s) did not return; exiting" << std::endl;
+                std::cerr.flush();
+                std::_Exit(1);
+            }
             for (std::thread &t : pool) t.join();
         } else {
             renderOn(sh, 0, 0);
         }
-        int rc = 0;
-        for (int r = 0; r < threads; ++r)
-            if (sh.status[(size_t)r]) {
-                std::cerr << "gpu " << r << ": " << sh.errors[(size_t)r] << std::endl;
-                rc = 1;
-            }
-        return rc;
+        return report();
     } catch (const std::exception &e) {
         std::cerr << e.what() << std::endl;
         return 1;

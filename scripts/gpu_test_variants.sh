@@ -13,3 +13,6 @@ RT_WF_WALK_STOP=1 RT_WF_WALK_MIN=40 RT_WF_MIN_RAYS=1 RT_WF_REFILL=8 \
 # kernels case by case, this runs the WHOLE parity suite on rt_wf_extend_rows_kernel)
 RT_WF_ROWS=1 \
   timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread | tail -2
+# (4) the -DRT_DEBUG_WALK build (make debugwalk): links and leaf ranges checked inside every kernel that walks the tree
+RT_HIP_LIB=$PWD/raytracer_amd/lib/variants/librt_hip_debugwalk.so \
+  timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread | tail -2

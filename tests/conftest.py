@@ -34,3 +34,27 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+_WALK_DEBUG_EXPORTS = ("rt_debug_walk_violations_per_pixel", "rt_debug_walk_violations_rl",
+                       "rt_debug_walk_violations_wavefront")
+
+
+@pytest.fixture(autouse=True)
+def _no_walk_violations(request):
+    """With a -DRT_DEBUG_WALK build of the launcher (make debugwalk; RT_HIP_LIB=raytracer_amd/lib/variants/
+    librt_hip_debugwalk.so) every link and leaf range a kernel follows is checked on the device; after each GPU test
+    the violation counters of every translation unit must be zero.  With the ordinary build this does nothing."""
+    yield
+    if "gpu" not in request.keywords:
+        return
+    import ctypes
+    from raytracer_amd import hiplib
+    L = hiplib._lib
+    if L is None or not hasattr(L, _WALK_DEBUG_EXPORTS[0]):
+        return
+    for name in _WALK_DEBUG_EXPORTS:
+        out = (ctypes.c_int * 4)()
+        assert getattr(L, name)(out) == 0, name
+        assert list(out) == [0, 0, 0, 0], (name, "link out of range / leaf beyond the triangle stream / packed loop on "
+                                                 "an unpacked scene", list(out))

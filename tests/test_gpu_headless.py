@@ -144,3 +144,36 @@ def test_headless_gpus_1_assembles_through_the_rccl_gather(tmp_path):
     assembled = np.fromfile(prefix + "_assembled.f16", np.float16).reshape(H, W, 4)
     assert np.array_equal(assembled.view(np.uint16), plain.view(np.uint16))
     assert "gpu 0: 128 x 72" in out
+
+
+@pytest.mark.parametrize("args,ends_filtered", [(["--filter", 3, "--keys", "2:SPACE"], False),
+                                                (["--filter", 0, "--keys", "1:SPACE,2:EQUAL"], True)])
+def test_headless_gpus_1_follows_the_scripted_filter_state(tmp_path, args, ends_filtered):
+    """SPACE toggles the filter and EQUAL / MINUS change its iterations WITHOUT restarting the accumulation (reference
+    src/glfw_setter.cpp:207-218).  The multi-GPU path must gather the image the frame's scripted state names (not a
+    process-wide static the GPU threads write at their own pace) and keep one tile grid / halo for the whole run: the
+    assembled frame equals the single-context run's, bit for bit."""
+    W, H = 128, 72
+    base = ["--size", f"{W}x{H}", "--frames", 4, "--bounces", 3] + args
+    prefix, _ = run_headless(tmp_path, "room.obj", *base)
+    plain = load_dump(prefix, W, H, ends_filtered)
+    prefix, _ = run_headless(tmp_path, "room.obj", *base, "--gpus", 1)
+    if ends_filtered:
+        assembled = np.fromfile(prefix + "_assembled.f16", np.float16).reshape(H, W, 4)
+        assert np.array_equal(assembled.view(np.uint16), plain["filtered"].view(np.uint16))
+    else:
+        assembled = np.fromfile(prefix + "_assembled.f32", np.float32).reshape(H, W, 4)
+        assert np.array_equal(assembled.view(np.uint32), plain["color"].view(np.uint32))
+
+
+def test_headless_exits_nonzero_when_a_gpu_thread_fails(tmp_path):
+    """--gpus 2 on a box with one GPU: the second thread cannot create its context; the first waits inside
+    ncclCommInitRank for a peer that never comes.  rt_headless must report the failing rank and exit non-zero instead of
+    hanging (it gives the other threads ten seconds, then leaves)."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs exactly one GPU")
+    cmd = [HEADLESS, assets.path("room.obj"), "--out", str(tmp_path / "frame"), "--size", "64x48", "--frames", 2, "--gpus", 2]
+    r = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=90)
+    assert r.returncode == 1, (r.returncode, r.stderr[-1500:])
+    assert "NO USABLE GPU (rt_create(1)" in r.stderr and "gpu 1:" in r.stderr

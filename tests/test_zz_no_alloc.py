@@ -54,3 +54,57 @@ def test_static_entry_point_equals_rt_trace_batch_twice_in_a_row():
         assert L.rt_trace_batch_static(ctx._h, ctypes.byref(q), 1, None) == -1
     finally:
         ctx.close()
+
+
+def test_static_entry_point_under_stream_capture():
+    """One of the callers the entry point is for: code under HIP graph capture.  On a caller-supplied stream in GLOBAL
+    capture mode (any hipMalloc / hipFree / synchronising call from this thread would invalidate the capture), one
+    rt_trace_batch_static call is recorded, instantiated and replayed twice: the replayed frames equal the frame the same
+    call renders directly, bit for bit.  (The call queues only memsets and kernel launches on the current stream.)"""
+    hip = ctypes.CDLL("libamdhip64.so.7")
+    vp = ctypes.c_void_p
+    hip.hipStreamBeginCapture.argtypes = [vp, ctypes.c_int]
+    hip.hipStreamEndCapture.argtypes = [vp, ctypes.POINTER(vp)]
+    hip.hipGraphInstantiate.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ctypes.c_size_t]
+    hip.hipGraphLaunch.argtypes = [vp, vp]
+    hip.hipGraphExecDestroy.argtypes = [vp]
+    hip.hipGraphDestroy.argtypes = [vp]
+    hip.hipStreamSynchronize.argtypes = [vp]
+    hip.hipStreamDestroy.argtypes = [vp]
+    ctx = hiplib.Context(0)
+    s = vp()
+    assert hip.hipStreamCreate(ctypes.byref(s)) == 0
+    graph, exe = vp(), vp()
+    try:
+        wl = workloads.Workload("room", 128, 96)
+        ctx.upload_scene(wl.buffers)
+        ctx.resize(wl.width, wl.height)
+        ctx.set_stream(s.value)
+        kw = dict(spp=3, max_bounces=4, flags=0, num_emitters=wl.num_emitters, static=True)
+        ctx.clear()
+        ctx.trace_samples(wl.rays, wl.eye, **kw)
+        want = {k: ctx.readback(v).copy() for k, v in dict(color=hiplib.IMAGE_COLOR, normal=hiplib.IMAGE_NORMAL,
+                                                           pos=hiplib.IMAGE_POSITION).items()}
+        assert np.isfinite(want["color"]).all() and (want["normal"] != 0).any()
+        ctx.clear()
+        ctx.sync()
+        assert hip.hipStreamBeginCapture(s, 0) == 0                   # hipStreamCaptureModeGlobal
+        ctx.trace_samples(wl.rays, wl.eye, **kw)                      # recorded, not run
+        assert hip.hipStreamEndCapture(s, ctypes.byref(graph)) == 0 and graph.value
+        assert hip.hipGraphInstantiate(ctypes.byref(exe), graph, None, None, 0) == 0
+        assert np.all(ctx.readback(hiplib.IMAGE_COLOR) == 0)          # nothing ran during the capture
+        for _ in range(2):
+            ctx.clear()
+            ctx.sync()
+            assert hip.hipGraphLaunch(exe, s) == 0
+            assert hip.hipStreamSynchronize(s) == 0
+            for k, v in dict(color=hiplib.IMAGE_COLOR, normal=hiplib.IMAGE_NORMAL, pos=hiplib.IMAGE_POSITION).items():
+                assert np.array_equal(ctx.readback(v).view(np.uint8), want[k].view(np.uint8)), k
+    finally:
+        if exe.value:
+            hip.hipGraphExecDestroy(exe)
+        if graph.value:
+            hip.hipGraphDestroy(graph)
+        ctx.set_stream(0)
+        hip.hipStreamDestroy(s)
+        ctx.close()
