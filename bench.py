@@ -35,6 +35,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+THROUGHPUT_NOTE = ("throughput: wall time of the K timed frames, queued back to back with `frames_in_flight` frames "
+                   "overlapping on the GPU, divided by K; `latency_ms_one_frame` is one frame on an otherwise idle GPU")
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 VALU_PEAK_TOPS_NOFMA = 78.6  # 157.3 TFLOP/s fp32 vector counts an FMA as 2; parity mode issues no FMA
 L2_RESIDENT_BYTES = 3 * 1024 * 1024  # the launcher's own threshold (rt_launcher.hip): hot scene bytes vs one XCD's 4 MiB L2
@@ -99,6 +101,34 @@ def alone_roofline(K, ctx, step, steps, wl, W, H, spp, filter_iters, scene_key, 
     if not r:
         return None
     return {"frames_in_flight_of_timed_region": before, **{k: r[k] for k in ("kernel", "achieved", "unit", "frac", "avg_launch_ms", "launches")}}
+
+
+def one_frame_latency(ctx, step, frames=10):
+    """Wall-clock time of ONE frame (trace + filter) from its first launch to its last kernel's end with nothing else on
+    the GPU: frames in flight set to 1, a sync before and after every frame, no profiling events.  Median of `frames`."""
+    ctx.sync()
+    before = ctx.frames_in_flight()
+    ctx.set_frames_in_flight(1)
+    try:
+        step()
+        ctx.sync()
+        times = []
+        for _ in range(frames):
+            ctx.sync()
+            t0 = time.perf_counter()
+            step()
+            ctx.sync()
+            times.append((time.perf_counter() - t0) * 1e3)
+        # throughput with one frame at a time: the same frames queued back to back, one sync at the end
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            step()
+        ctx.sync()
+        back_to_back = (time.perf_counter() - t0) * 1e3 / frames
+    finally:
+        ctx.set_frames_in_flight(before if os.environ.get("RT_PIPELINE") else 0)
+    return round(float(np.median(times)), 4), round(back_to_back, 4)
 
 
 def with_alone(rl, alone):
@@ -249,9 +279,13 @@ def run_case(K, parallel, ctx, device, wl, scene_key, W, H, spp, bounces, filter
     cnt, tm = ctx.counters(), ctx.timings()
     ctx.profile(False)
     rays_per_frame = float(cnt.rays) / steps
+    in_flight = ctx.frames_in_flight()
     rl = with_alone(roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, stop_at_root),
                     alone_roofline(K, ctx, step, steps, wl, W, H, spp, filter_iters, scene_key, stop_at_root))
-    out = {"ms_per_frame": round(elapsed * 1e3 / steps, 4), "steps": steps, "warmup": warmup,
+    latency, alone_b2b = one_frame_latency(ctx, step, max(3, min(10, steps)))
+    out = {"ms_per_frame": round(elapsed * 1e3 / steps, 4), "ms_per_frame_is": THROUGHPUT_NOTE, "frames_in_flight": in_flight,
+           "latency_ms_one_frame": latency, "ms_per_frame_one_frame_at_a_time": alone_b2b,
+           "steps": steps, "warmup": warmup,
            "value": round(float(cnt.rays) / elapsed / 1e6, 3), "unit": "Mrays/s",
            "rays_per_frame": rays_per_frame, "node_visits_per_frame": cnt.node_visits / steps,
            "tri_tests_per_frame": cnt.tri_tests / steps,
@@ -353,6 +387,10 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # how the tiles of the N-rank frame reach rank 0: "local" (N = 1), "rccl" (rt_gather_tiles, the product path),
+    # "gloo-fallback" (rt_comm_init failed on some rank), "gloo-rehearsal" (RT_BENCH_COLLECTIVES=gloo)
+    gather_state = {"mode": "local" if world == 1 else ("gloo-rehearsal" if rehearsal else "rccl"), "errors": None}
+
     def tiled_run(wl, W, H, spp, bounces, filt, steps, warmup, mf):
         """K timed frames of the tiled N-rank path (N = 1: one tile, the gather is a local copy when a communicator
         exists).  Returns (elapsed max over ranks, per-rank counters / timings, frame, backend)."""
@@ -364,19 +402,32 @@ def main():
             # The launcher's own RCCL gather.  Should a rank fail to join (never seen; 8-GPU nodes are not ours to
             # test on), every rank falls back to the blocking torch.distributed gather through host memory (a gloo
             # group) rather than losing the run: same frame, slower exchange, and the JSON line says so.
-            ok = 1.0
+            ok, why = 1.0, ""
             try:
                 backend.init_comm(rank, world, dist)
             except Exception as e:  # noqa: BLE001
-                print(f"[bench] rank {rank}: rt_comm_init failed: {e}", file=sys.stderr)
+                why = f"{type(e).__name__}: {e}"
                 ok = 0.0
             agree = torch.tensor([ok], device=device)
             dist.all_reduce(agree, op=dist.ReduceOp.MIN)
             if float(agree[0]) == 0.0:
+                # LOUD: every rank's RCCL error on stderr, and the JSON line says "gather": "gloo-fallback" at top level
+                reasons = [None] * world
+                dist.all_gather_object(reasons, why or "joined (another rank did not)")
+                if rank == 0:
+                    print("[bench] WARNING: the launcher's RCCL communicator (rt_comm_init) could not be set up; the tiles are "
+                          "gathered through host memory over gloo instead — this is NOT the product path:", file=sys.stderr)
+                    for r, text in enumerate(reasons):
+                        print(f"[bench]   rank {r}: {text}", file=sys.stderr)
+                    sys.stderr.flush()
+                gather_state["mode"] = "gloo-fallback"
+                gather_state["errors"] = reasons
                 if backend.comm_ready:
                     ctx.comm_destroy()
                     backend.comm_ready = False
                 gather_group = _GlooGather(dist)
+            else:
+                gather_state["mode"] = "rccl"
         frame = parallel.TiledFrame(backend, W, H, rank, world, hiplib.IMAGE_FILTERED if filt else hiplib.IMAGE_COLOR)
 
         def step():
@@ -459,7 +510,13 @@ def main():
                                                                        max_follows=max_follows), wl, W, H, a.spp)
     elapsed, cnt, tm, frame, backend, settle, step = tiled_run(wl, W, H, a.spp, a.bounces, a.filter, a.steps, a.warmup, max_follows)
     ctx.profile(False)
+    in_flight = ctx.frames_in_flight()
     alone = alone_roofline(K, ctx, step, a.steps, wl, W, H, a.spp, a.filter, scene_key, stop_at_root or 0)
+    latency, alone_b2b = one_frame_latency(ctx, step, max(3, min(10, a.steps)))
+    if dist is not None:  # the slowest rank's
+        lat = torch.tensor([latency, alone_b2b], dtype=torch.float64, device="cpu" if rehearsal else device)
+        dist.all_reduce(lat, op=dist.ReduceOp.MAX)
+        latency, alone_b2b = round(float(lat[0]), 4), round(float(lat[1]), 4)
 
     frame_sha = None
     if os.environ.get("RT_BENCH_CHECKSUM") and rank == 0:  # rehearsal aid: every N must assemble the same picture
@@ -545,6 +602,9 @@ def main():
         "metric": "Mrays/s (trace+filter), scene.obj 1080p 4spp" if headline else f"Mrays/s (trace+filter), {frame_name}",
         "value": round(mrays, 3), "unit": "Mrays/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(ms_per_step, 4), "ms_per_frame": round(ms_per_step, 4),
+        "ms_per_step_is": THROUGHPUT_NOTE, "frames_in_flight": in_flight,
+        "latency_ms_one_frame": latency, "ms_per_frame_one_frame_at_a_time": alone_b2b,
+        "gather": gather_state["mode"], **({"gather_errors": gather_state["errors"]} if gather_state["errors"] else {}),
         "higher_is_better": True, "scaling": a.scaling if world > 1 else "strong", "vs_baseline": None, "dtype": "f32",
         "data": ("the reference's own res/scene.obj (fixture copy) + harness quad light; no external data" if a.scene == "scene"
                  else "synthetic lattice of the reference's res/suzanne.obj" if lattice else f"the reference's own {a.scene}.obj"),

@@ -39,6 +39,9 @@ struct rt_ctx {
     bool cellsStale = true;
     DevBuf spec;          // decision-tree table of the row-mode walk (RtScene::spec); hasSpec says whether it is valid
     bool hasSpec = false;
+    DevBuf triPairs, slotTri; // packed scenes: the leaves' triangles as pair records + slot -> triangle (RtScene::triPairs)
+    int numSlots = 0;         // slots the packed node records address (every leaf starts at an even slot)
+    bool pairsValid = false;  // triPairs / slotTri hold the uploaded nodes' leaves of the uploaded triangles
     int numNodes = 0, numTris = 0, numMtls = 0, numEmitters = 0;
     int maxTriEnd = 0; // largest firstTri+numTris over the nodes, checked against numTris at launch
 

@@ -4,11 +4,14 @@
 //   boxes   float4[2*N]   node i → {min.xyz, bits(w0)}, {max.xyz, bits(w1)}                 32 B, 32-B aligned
 //           packed form (every leaf has <= 32 triangles and the triangle stream < 2^26 records, true for any tree
 //           the reference's builder makes up to 67 M triangles): w0 = missNext; w1 = hitNext for an inner node,
-//           0x80000000 | (numTris-1) << 26 | firstTri for a leaf (whose hitNext equals its missNext), so that one
+//           0x80000000 | (numTris-1) << 26 | firstSlot for a leaf (whose hitNext equals its missNext), so that one
 //           32-byte read gives the box, both links and the leaf range;
 //           plain form (anything else): w0 = hitNext, w1 = missNext, leaf range from `leaves`
 //   leaves  int2[N]       node i → {firstTri, numTris}                                    8 B
 //   tris48  float4[3*T]   triangle j → {v0,0}, {v1-v0,0}, {v2-v0,0}                      48 B, 16-B aligned
+//   triPairs float4[5*S/2] packed scenes: the same values leaf by leaf, two triangles per 80-B record, interleaved
+//           component by component for packed fp32 arithmetic (RtScene::triPairs); a packed leaf word's range is in
+//           SLOTS of this stream (every leaf starts at an even slot), slotTri[slot] = triangle index
 //   tris128 the reference's 128-B triangle records, untouched (normals, mtlIndex, ...)   shading only
 //   mtls    the reference's 32-B material records; emitters: 128-B records
 //   spec    uint16[32*N] decision-tree table of the row-mode walk (small packed trees only, see RtScene::spec)
@@ -69,6 +72,12 @@ struct RtScene {
     // at once), 15..30: the nodes the walk can stand on after four decisions; 0xFFFF = the walk has ended there.
     // Entry 0: bit p set = position p (0..14) has a node; entry 31: bit p set = that node is a leaf.
     const uint16_t *spec;
+    // Packed scenes only (trace3_device.h: testPair): the leaves' triangles as 80-byte PAIR records {v0, e1, e2 of slots
+    // 2P and 2P+1, component by component}, every leaf starting at an even slot (a packed leaf word holds its first
+    // slot), and the triangle index of every slot (-1: the padding half of a leaf of odd size).
+    const float4 *triPairs;
+    const int *slotTri;
+    int numSlots;
 };
 #define RT_SPEC_MAX_NODES 896
 #define RT_SPEC_STRIDE 32

@@ -31,6 +31,8 @@ hipError_t rtLaunchTonemap(const float4 *colorF32, const uint2 *colorF16, uint32
 hipError_t rtLaunchFlatLevels(const RtFlatCells &rec, uint8_t *level, uint2 *texels, int W, int H, int passes,
                               const float *c_phi, const float *n_phi, const float *p_phi, hipStream_t stream);
 int rtAtrousMaxStep();
+hipError_t rtLaunchBuildPairs(const float4 *boxes, const int2 *leaves, int numNodes, const float4 *tris48, float4 *pairs,
+                              int *slotTri, int numSlots, hipStream_t stream); // wavefront.hip
 // rt_comm.hip
 void rtCommQuiesce(rt_ctx *c);
 void rtCommRelease(rt_ctx *c);
@@ -186,6 +188,29 @@ void rtMarkKernel(void *opaque, int kind, bool begin) {
     } else {
         spanStop(c, cur);
     }
+}
+
+// The pair stream of a packed scene (rt_device.h: RtScene::triPairs) is made on the device from the re-packed node and
+// triangle records, as soon as both streams are there and fit together (whichever is uploaded last): launches — the
+// no-allocation entry point among them — find it ready.  A node stream whose leaves reach beyond the triangle stream
+// gets none; such a scene is refused at launch anyway (RT_ECORRUPT).
+static int rebuildPairs(rt_ctx *c) {
+    c->pairsValid = false;
+    if (c->packedLeaves && c->boxes.p && c->numSlots <= 0) { // a tree without leaves: nothing to pair, nothing is ever read
+        c->pairsValid = true;
+        return RT_OK;
+    }
+    if (!c->packedLeaves || !c->boxes.p || !c->tris48.p || c->maxTriEnd > c->numTris) return RT_OK;
+    int r;
+    if ((r = ensure(c, c->triPairs, (size_t)(c->numSlots / 2) * 80)) || (r = ensure(c, c->slotTri, (size_t)c->numSlots * 4)))
+        return r;
+    hipError_t e = rtLaunchBuildPairs((const float4 *)c->boxes.p, (const int2 *)c->leaves.p, c->numNodes,
+                                      (const float4 *)c->tris48.p, (float4 *)c->triPairs.p, (int *)c->slotTri.p,
+                                      c->numSlots, c->stream);
+    if (e != hipSuccess) return hipFail(c, e, "pair stream build");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->pairsValid = true;
+    return RT_OK;
 }
 
 extern "C" {
@@ -346,7 +371,7 @@ void rt_destroy(rt_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     DevBuf *all[] = {&c->boxes, &c->leaves, &c->tris48, &c->tris128, &c->mtls, &c->emitters, &c->color, &c->normal,
                      &c->pos, &c->filt[0], &c->filt[1], &c->tridx, &c->visits, &c->stats, &c->ldr, &c->counters,
-                     &c->spec, &c->flatFlag, &c->flatColor, &c->flatNormal, &c->flatPos, &c->flatLevel, &c->flatTexels};
+                     &c->spec, &c->triPairs, &c->slotTri, &c->flatFlag, &c->flatColor, &c->flatNormal, &c->flatPos, &c->flatLevel, &c->flatTexels};
     for (rt_ctx::Lane &L : c->lane) {
         for (DevBuf &b : L.wfState) releaseBuf(b);
         for (DevBuf &b : L.wfRay) releaseBuf(b);
@@ -415,8 +440,13 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
                 innerEndsWalk = true;
             }
         }
-        const bool packed = leafLinksEqual && !innerEndsWalk && maxLeaf <= 32 && maxEnd <= (1ll << 26);
+        // packed leaf words address SLOTS of the pair stream: every leaf starts at an even slot (rt_device.h)
+        long long totalSlots = 0;
+        for (size_t i = 0; i < n; ++i)
+            if (src[i].numTris > 0) totalSlots += ((long long)src[i].numTris + 1) & ~1ll;
+        const bool packed = leafLinksEqual && !innerEndsWalk && maxLeaf <= 32 && totalSlots <= (1ll << 26);
         maxEnd = 0;
+        long long slotAt = 0;
         for (size_t i = 0; i < n; ++i) {
             const RtNode48 &s = src[i];
             if (s.hitNext < -1 || s.hitNext >= (long long)n || s.missNext < -1 || s.missNext >= (long long)n)
@@ -427,7 +457,8 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
             int w0 = s.hitNext, w1 = s.missNext;
             if (packed) {
                 w0 = s.missNext;
-                w1 = s.numTris > 0 ? (int)(0x80000000u | ((unsigned)(s.numTris - 1) << 26) | (unsigned)s.firstTri) : s.hitNext;
+                w1 = s.numTris > 0 ? (int)(0x80000000u | ((unsigned)(s.numTris - 1) << 26) | (unsigned)slotAt) : s.hitNext;
+                if (s.numTris > 0) slotAt += ((long long)s.numTris + 1) & ~1ll;
             }
             float hb, mb;
             std::memcpy(&hb, &w0, 4);
@@ -472,7 +503,9 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
         c->numNodes = (int)n;
         c->maxTriEnd = (int)maxEnd;
         c->packedLeaves = packed;
-        return RT_OK;
+        c->numSlots = packed ? (int)totalSlots : 0;
+        c->pairsValid = false;
+        return rebuildPairs(c);
     }
     case RT_SLOT_TRIANGLES: {
         if (nbytes % sizeof(RtTri128)) return fail(c, RT_EINVAL, "rt_upload: triangle stream is not a multiple of 128 bytes");
@@ -490,7 +523,8 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
         if ((r = uploadTo(c, c->tris48, t48.data(), t48.size() * sizeof(float4)))) return r;
         if ((r = uploadTo(c, c->tris128, bytes, nbytes))) return r;
         c->numTris = (int)n;
-        return RT_OK;
+        c->pairsValid = false;
+        return rebuildPairs(c);
     }
     case RT_SLOT_MATERIALS:
         if (nbytes % sizeof(RtMtl)) return fail(c, RT_EINVAL, "rt_upload: material stream is not a multiple of 32 bytes");
@@ -606,6 +640,9 @@ void fillScene(const rt_ctx *c, RtScene &sc, RtImages &img) {
     sc.cacheNodes = 0;
     sc.packedLeaves = c->packedLeaves ? 1 : 0;
     sc.spec = c->hasSpec ? (const uint16_t *)c->spec.p : nullptr;
+    sc.triPairs = (const float4 *)c->triPairs.p;
+    sc.slotTri = (const int *)c->slotTri.p;
+    sc.numSlots = c->numSlots;
     img.color = (float4 *)c->color.p;
     img.normal = (uint32_t *)c->normal.p;
     img.pos = (uint2 *)c->pos.p;
@@ -848,6 +885,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
         if (c->maxTriEnd > c->numTris)
             return fail(c, RT_ECORRUPT, "rt_trace: a leaf references triangles beyond the uploaded triangle stream");
+        if (c->packedLeaves && !c->pairsValid) return fail(c, RT_ESTATE, "rt_trace: the scene's pair stream is missing (upload failed?)");
         RtScene sc;
         RtImages img;
         fillScene(c, sc, img);
@@ -935,6 +973,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
         if (c->maxTriEnd > c->numTris)
             return fail(c, RT_ECORRUPT, "rt_trace: a leaf references triangles beyond the uploaded triangle stream");
+        if (c->packedLeaves && !c->pairsValid) return fail(c, RT_ESTATE, "rt_trace: the scene's pair stream is missing (upload failed?)");
         for (int slot = RT_SLOT_VORONOI_NORMALS; slot <= RT_SLOT_QVISITS; ++slot)
             if (!c->raw[slot].p) return fail(c, RT_ESTATE, "rt_trace: the Q-table kernel needs slots 7..10 uploaded");
         if (p->numPoints <= 0 || p->maxTheta <= 0 || p->maxPhi <= 0 ||
@@ -1052,6 +1091,7 @@ int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const
         return fail(c, RT_ESTATE, "rt_trace_batch_static: nodes, triangles and materials must be uploaded first");
     if (c->maxTriEnd > c->numTris)
         return fail(c, RT_ECORRUPT, "rt_trace_batch_static: a leaf references triangles beyond the uploaded triangle stream");
+    if (c->packedLeaves && !c->pairsValid) return fail(c, RT_ESTATE, "rt_trace_batch_static: the scene's pair stream is missing (upload failed?)");
     const size_t tilePixels = (size_t)(r.x1 - r.x0) * (size_t)(r.y1 - r.y0);
     if (tilePixels * (size_t)n > (size_t)RT_STATIC_MAX_PATHS)
         return fail(c, RT_EINVAL, "rt_trace_batch_static: tile pixels x samples = " + std::to_string(tilePixels * (size_t)n) +

@@ -238,6 +238,141 @@ __device__ __forceinline__ void testLeaf(const float4 *__restrict__ tris48, int 
     }
 }
 
+// ---------------------------------------------------------------- two triangles per test (packed fp32)
+// For packed scenes the launcher keeps the leaves' triangles a second time as PAIRS (rt_launcher.hip: rtBuildPairs):
+// every leaf starts at an even "slot", slots 2P and 2P+1 share one 80-byte record
+//   q0 = {v0.x_a, v0.x_b, v0.y_a, v0.y_b}  q1 = {v0.z_a, v0.z_b, e1.x_a, e1.x_b}  q2 = {e1.y_a, e1.y_b, e1.z_a, e1.z_b}
+//   q3 = {e2.x_a, e2.x_b, e2.y_a, e2.y_b}  q4 = {e2.z_a, e2.z_b, 0, 0}
+// (a leaf of odd size ends with an all-zero half: det = 0 and t = 0 * inf = NaN, which `t >= 0` never accepts), and
+// sc.slotTri[slot] is the triangle's index in the uploaded stream.  The interleaving puts the same component of two
+// triangles into one 64-bit register pair straight from the load, so that intersectTriangle (geometry.glsl:31-51) runs
+// for both at once on v_pk_mul_f32 / v_pk_add_f32 — IEEE fp32 per half, the same operations in the same order, no
+// contraction: bit-identical to two single tests — at 24 + 18 packed instructions per PAIR where the single test
+// issues 24 + 18 per triangle.  Round 2 had left this to the SLP vectoriser, which paid for every pair it formed with
+// register-pairing moves (Makefile: -fno-slp-vectorize); here the pairs exist by layout and there are no moves.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct RayP { // a ray with every component in both halves of a register pair
+    f2 ox, oy, oz, dx, dy, dz;
+};
+__device__ __forceinline__ f2 splat2(float v) {
+    f2 r = {v, v};
+    return r;
+}
+__device__ __forceinline__ RayP makeRayP(f3 origin, f3 dir) {
+    RayP r = {splat2(origin.x), splat2(origin.y), splat2(origin.z), splat2(dir.x), splat2(dir.y), splat2(dir.z)};
+    return r;
+}
+struct PairTerms { // what both halves of a pair test share with the code that picks the winner
+    f2 det, u, v, qx, qy, qz, e2x, e2y, e2z;
+    bool inA, inB;
+};
+__device__ __forceinline__ void pairTerms(const float4 q0, const float4 q1, const float4 q2, const float4 q3,
+                                          const float4 q4, const RayP &r, PairTerms &T) {
+    const f2 v0x = {q0.x, q0.y}, v0y = {q0.z, q0.w}, v0z = {q1.x, q1.y};
+    const f2 e1x = {q1.z, q1.w}, e1y = {q2.x, q2.y}, e1z = {q2.z, q2.w};
+    const f2 e2x = {q3.x, q3.y}, e2y = {q3.z, q3.w}, e2z = {q4.x, q4.y};
+    // pvec = cross(dir, e2); det = dot(e1, pvec)                                   geometry.glsl:33-34
+    const f2 px = r.dy * e2z - r.dz * e2y, py = r.dz * e2x - r.dx * e2z, pz = r.dx * e2y - r.dy * e2x;
+    T.det = e1x * px + (e1y * py + e1z * pz);
+    // tvec = origin - v0; u = dot(tvec, pvec)                                      :37-38
+    const f2 tx = r.ox - v0x, ty = r.oy - v0y, tz = r.oz - v0z;
+    T.u = tx * px + (ty * py + tz * pz);
+    // qvec = cross(tvec, e1); v = dot(dir, qvec)                                   :41-42
+    T.qx = ty * e1z - tz * e1y;
+    T.qy = tz * e1x - tx * e1z;
+    T.qz = tx * e1y - ty * e1x;
+    T.v = r.dx * T.qx + (r.dy * T.qy + r.dz * T.qz);
+    const f2 uv = T.u + T.v;
+    T.e2x = e2x;
+    T.e2y = e2y;
+    T.e2z = e2z;
+    // the rejections of :35-36, :39-40, :43-44
+    T.inA = !(T.det.x < 0.0f) & !(T.u.x < 0.0f || T.u.x > T.det.x) & !(T.v.x < 0.0f || uv.x > T.det.x);
+    T.inB = !(T.det.y < 0.0f) & !(T.u.y < 0.0f || T.u.y > T.det.y) & !(T.v.y < 0.0f || uv.y > T.det.y);
+}
+// intersectTriangles' step (trace3.cs:176-183) for slots `slot` and `slot + 1`, in that order, strict `<`.
+__device__ __forceinline__ void testPair(const float4 q0, const float4 q1, const float4 q2, const float4 q3, const float4 q4,
+                                         int slot, const RayP &r, float &nearest, int &hitSlot, float &hitT, float &hitU,
+                                         float &hitV) {
+    PairTerms T;
+    pairTerms(q0, q1, q2, q3, q4, r, T);
+    if (T.inA | T.inB) { // (rare: only a candidate inside its triangle pays for t and the division)
+        const f2 tn = T.e2x * T.qx + (T.e2y * T.qy + T.e2z * T.qz); // dot(e2, qvec), :46
+        if (T.inA) {
+            const float invDet = 1.0f / T.det.x;
+            const float t = tn.x * invDet;
+            if (t >= 0.0f && t < nearest) {
+                nearest = t;
+                hitT = t;
+                hitU = T.u.x * invDet;
+                hitV = T.v.x * invDet;
+                hitSlot = slot;
+            }
+        }
+        if (T.inB) {
+            const float invDet = 1.0f / T.det.y;
+            const float t = tn.y * invDet;
+            if (t >= 0.0f && t < nearest) {
+                nearest = t;
+                hitT = t;
+                hitU = T.u.y * invDet;
+                hitV = T.v.y * invDet;
+                hitSlot = slot + 1;
+            }
+        }
+    }
+}
+// The pair as a pure function (row mode, wavefront.hip): the better of its two candidates nearer than `nearest` — the
+// smaller t, the lower slot on equal t — as a key (bits of t; -0.0 keyed as +0.0; 0xFFFFFFFF: none), its t, u, v, slot.
+__device__ __forceinline__ unsigned pairCandidate(const float4 q0, const float4 q1, const float4 q2, const float4 q3,
+                                                  const float4 q4, int slot, const RayP &r, float nearest, float &t,
+                                                  float &u, float &v, int &at) {
+    PairTerms T;
+    pairTerms(q0, q1, q2, q3, q4, r, T);
+    unsigned key = 0xFFFFFFFFu;
+    t = u = v = 0.0f;
+    at = 0x7FFFFFFF;
+    if (T.inA | T.inB) {
+        const f2 tn = T.e2x * T.qx + (T.e2y * T.qy + T.e2z * T.qz);
+        if (T.inA) {
+            const float invDet = 1.0f / T.det.x;
+            const float ta = tn.x * invDet;
+            if (ta >= 0.0f && ta < nearest) {
+                key = __float_as_uint(ta + 0.0f);
+                t = ta;
+                u = T.u.x * invDet;
+                v = T.v.x * invDet;
+                at = slot;
+            }
+        }
+        if (T.inB) {
+            const float invDet = 1.0f / T.det.y;
+            const float tb = tn.y * invDet;
+            if (tb >= 0.0f && tb < nearest && __float_as_uint(tb + 0.0f) < key) { // strict: on equal t slot a stays
+                key = __float_as_uint(tb + 0.0f);
+                t = tb;
+                u = T.u.y * invDet;
+                v = T.v.y * invDet;
+                at = slot + 1;
+            }
+        }
+    }
+    return key;
+}
+// intersectTriangles (trace3.cs:172-186) over the `count` slots from `firstSlot` (even): two pair records (10 aligned
+// 16-byte loads, four triangles) are requested before the first is tested.
+__device__ __forceinline__ void testLeafPairs(const float4 *__restrict__ pairs, int firstSlot, int count, const RayP &r,
+                                              float &nearest, int &hitSlot, float &hitT, float &hitU, float &hitV) {
+    const int p0 = firstSlot >> 1, np = (count + 1) >> 1;
+    for (int k = 0; k < np; k += 2) {
+        const int pa = p0 + k, pb = p0 + min(k + 1, np - 1);
+        const float4 a0 = pairs[5 * pa], a1 = pairs[5 * pa + 1], a2 = pairs[5 * pa + 2], a3 = pairs[5 * pa + 3], a4 = pairs[5 * pa + 4];
+        const float4 b0 = pairs[5 * pb], b1 = pairs[5 * pb + 1], b2 = pairs[5 * pb + 2], b3 = pairs[5 * pb + 3], b4 = pairs[5 * pb + 4];
+        testPair(a0, a1, a2, a3, a4, 2 * pa, r, nearest, hitSlot, hitT, hitU, hitV);
+        if (k + 1 < np) testPair(b0, b1, b2, b3, b4, 2 * (p0 + k + 1), r, nearest, hitSlot, hitT, hitU, hitV);
+    }
+}
+
 // ---------------------------------------------------------------- watertight variant (opt-in)
 // RT_FLAG_WATERTIGHT: the ray-triangle test of Woop, Benthin and Wald ("Watertight Ray/Triangle Intersection",
 // JCGT 2013) in place of the reference's Möller-Trumbore.  NOT the reference's arithmetic (a ray through a shared edge or
@@ -394,6 +529,7 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
     hit.t = hit.u = hit.v = 0.0f;
     bool ok = true;
     const bool ltx = invdir.x < 0.0f, lty = invdir.y < 0.0f, ltz = invdir.z < 0.0f;
+    const RayP rayP = makeRayP(origin, dir);
     for (;;) {
         int leafFirst = 0, leafCount = 0;
         if constexpr (NODES == NODES_PLAIN) {
@@ -467,13 +603,25 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
             leafCount = leafWord != 0 ? ((leafWord >> 26) & 31) + 1 : 0;
         }
         if (leafCount <= 0) break;
-        RT_WALK_CHECK(leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numTris, 1, { next = -1; break; });
-        if (WATERTIGHT)
-            testLeafWt(sc.tris128, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
-        else
-            testLeaf<true>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
+        if constexpr (NODES == NODES_PLAIN) { // leaf ranges are triangle indices
+            RT_WALK_CHECK(leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numTris, 1, { next = -1; break; });
+            if (WATERTIGHT)
+                testLeafWt(sc.tris128, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
+            else
+                testLeaf<true>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
+        } else { // packed records: leaf ranges are slots of the pair stream
+            RT_WALK_CHECK(leafFirst >= 0 && !(leafFirst & 1) && (long long)leafFirst + leafCount <= (long long)sc.numSlots, 1,
+                          { next = -1; break; });
+            if (WATERTIGHT) { // (the watertight test reads the 128-byte records: back to triangle indices)
+                const int firstTri = sc.slotTri[leafFirst];
+                testLeafWt(sc.tris128, firstTri, firstTri + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
+            } else {
+                testLeafPairs(sc.triPairs, leafFirst, leafCount, rayP, nearest, hit.tridx, hit.t, hit.u, hit.v);
+            }
+        }
         tests += (unsigned)leafCount;
     }
+    if (NODES != NODES_PLAIN && !WATERTIGHT && hit.tridx >= 0) hit.tridx = sc.slotTri[hit.tridx];
     c.lastIterations = iterations;
     c.rays++;
     c.visits += (unsigned)iterations;

@@ -603,8 +603,13 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             for (int o = 32; o; o >>= 1) d = max(d, __shfl_xor(d, o, 64));
             wtWalk += d;
         } const long long c2 = clock64(); wtWalkC += c2 - c1;)
-        RT_WALK_CHECK(!(active && leafCount > 0) || (leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numTris), 1,
-                      { leafCount = 0; next = -1; });
+        // Leaf ranges: triangle indices for plain records, SLOTS of the pair stream for packed ones (rt_device.h).  The
+        // (opt-in) watertight test reads the 128-byte triangle records, so it translates the range back first.
+        constexpr bool PAIRS = NODES != NODES_PLAIN && !WATERTIGHT; // this kernel tests two triangles at a time
+        RT_WALK_CHECK(!(active && leafCount > 0) ||
+                          (leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)(NODES == NODES_PLAIN ? sc.numTris : sc.numSlots)),
+                      1, { leafCount = 0; next = -1; });
+        if (NODES != NODES_PLAIN && WATERTIGHT && active && leafCount > 0) leafFirst = sc.slotTri[leafFirst];
         // phase 2: the leaves' triangles (geometry.glsl:31-51, trace3.cs:172-186), shared out over the wave.
         // Lanes hold leaves of 1..32 triangles (or none); testing "my leaf" lane by lane leaves most lanes idle
         // (measured: 38 % of the lanes active on room.obj, 20 % on scene.obj, and the kernel is VALU-issue
@@ -614,7 +619,8 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         // smallest t below the ray's current nearest (strict `<`, trace3.cs:177).
         bool shared = false;
         if (coopMode != 0) {
-            const int cnt = (active && leafCount > 0) ? leafCount : 0;
+            // entries of the wave's work list: (ray, triangle) — or, with the pair stream, (ray, pair of triangles)
+            const int cnt = (active && leafCount > 0) ? (PAIRS ? (leafCount + 1) >> 1 : leafCount) : 0;
             const unsigned long long holders = __ballot(cnt > 0);
             const int incl = waveInclusiveScan(cnt);
             const int totalTests = __builtin_amdgcn_readlane(incl, 63);
@@ -625,13 +631,13 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 shared = ((totalTests + 63) >> 6) * p.coopA + p.coopB < 4 * waveMaxNonNegative(cnt);
             if (shared) {
                 WT(wtCoop++; wtPairs += totalTests;)
-                // Pairs are numbered ray after ray (g = exclusive prefix of the leaf sizes + k).  Which ray pair g
-                // belongs to is found from a bit string with a one at every ray's first pair: the number of ones
-                // at or below g, minus one, is the rank of the ray among the leaf-holding lanes.
+                // Entries are numbered ray after ray (g = exclusive prefix of the rays' entry counts + k).  Which ray
+                // entry g belongs to is found from a bit string with a one at every ray's first entry: the number of
+                // ones at or below g, minus one, is the rank of the ray among the leaf-holding lanes.
                 const int excl = incl - cnt;
                 const int rank = __popcll(holders & lanesBelow);
                 if (cnt > 0) {
-                    ws->first[rank] = leafFirst - excl;
+                    ws->first[rank] = (PAIRS ? leafFirst >> 1 : leafFirst) - excl;
                     ws->ro[rank] = make_float4(origin.x, origin.y, origin.z, nearest);
                     ws->rd[rank] = make_float4(dir.x, dir.y, dir.z, 0.0f);
                     ws->key[rank] = ~0ull;
@@ -641,61 +647,104 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 WT(const long long c3 = clock64(); wtcSetup += c3 - c2;)
-                // rounds of 64 pairs; the triangle of the next round is requested before this round's is tested
+                // rounds of 64 entries; the record of the next round's entry is requested before this round's is tested
                 const unsigned long long atOrBelow = (2ull << lane) - 1ull;
                 int rankBase = -1; // rank of the last ray that starts before this round
                 unsigned long long heads = ws->heads[0];
-                // (RT_FLAG_WATERTIGHT: v0..v2 are the three vertices from the 128-byte records instead of {v0, e1, e2})
-                const float4 *triData = WATERTIGHT ? reinterpret_cast<const float4 *>(sc.tris128) : sc.tris48;
-                constexpr int triStride = WATERTIGHT ? 8 : 3;
-                struct Pair { // pair g of the list: ray of rank o, triangle tri
-                    int g, o, tri;
-                    float4 v0, v1, v2;
-                };
-                Pair pa, pb; // the pair of this round and the pair of the next, by turns (no copying between rounds)
-                pa.g = lane, pa.o = 0, pa.tri = 0;
-                pa.v0 = pa.v1 = pa.v2 = make_float4(0, 0, 0, 0);
-                pb = pa;
-                if (pa.g < totalTests) {
-                    pa.o = rankBase + __popcll(heads & atOrBelow);
-                    pa.tri = ws->first[pa.o] + pa.g;
-                    pa.v0 = triData[triStride * pa.tri];
-                    pa.v1 = triData[triStride * pa.tri + 1];
-                    pa.v2 = triData[triStride * pa.tri + 2];
-                }
-                // one round: request the triangle of the next round's pair, then test this round's
-                auto round = [&](const Pair &cur, Pair &nxt, int base) {
-                    nxt.g = cur.g + 64;
-                    rankBase += __popcll(heads);
-                    if (base + 64 < totalTests) heads = ws->heads[(base >> 6) + 1];
-                    if (nxt.g < totalTests) {
-                        nxt.o = rankBase + __popcll(heads & atOrBelow);
-                        nxt.tri = ws->first[nxt.o] + nxt.g;
-                        nxt.v0 = triData[triStride * nxt.tri];
-                        nxt.v1 = triData[triStride * nxt.tri + 1];
-                        nxt.v2 = triData[triStride * nxt.tri + 2];
+                if constexpr (PAIRS) {
+                    struct Entry { // entry g of the list: ray of rank o, pair record P (slots 2P and 2P + 1)
+                        int g, o, P;
+                        float4 q0, q1, q2, q3, q4;
+                    };
+                    Entry ea, eb; // this round's entry and the next round's, by turns (no copying between rounds)
+                    ea.g = lane, ea.o = 0, ea.P = 0;
+                    ea.q0 = ea.q1 = ea.q2 = ea.q3 = ea.q4 = make_float4(0, 0, 0, 0);
+                    eb = ea;
+                    if (ea.g < totalTests) {
+                        ea.o = rankBase + __popcll(heads & atOrBelow);
+                        ea.P = ws->first[ea.o] + ea.g;
+                        ea.q0 = sc.triPairs[5 * ea.P];
+                        ea.q1 = sc.triPairs[5 * ea.P + 1];
+                        ea.q2 = sc.triPairs[5 * ea.P + 2];
+                        ea.q3 = sc.triPairs[5 * ea.P + 3];
+                        ea.q4 = sc.triPairs[5 * ea.P + 4];
                     }
-                    if (cur.g < totalTests) {
-                        const float4 ro = ws->ro[cur.o], rd = ws->rd[cur.o];
-                        float tn = ro.w, tt = 0.0f, tu = 0.0f, tv = 0.0f;
-                        int th = -1;
-                        if (WATERTIGHT)
+                    auto round = [&](const Entry &cur, Entry &nxt, int base) {
+                        nxt.g = cur.g + 64;
+                        rankBase += __popcll(heads);
+                        if (base + 64 < totalTests) heads = ws->heads[(base >> 6) + 1];
+                        if (nxt.g < totalTests) {
+                            nxt.o = rankBase + __popcll(heads & atOrBelow);
+                            nxt.P = ws->first[nxt.o] + nxt.g;
+                            nxt.q0 = sc.triPairs[5 * nxt.P];
+                            nxt.q1 = sc.triPairs[5 * nxt.P + 1];
+                            nxt.q2 = sc.triPairs[5 * nxt.P + 2];
+                            nxt.q3 = sc.triPairs[5 * nxt.P + 3];
+                            nxt.q4 = sc.triPairs[5 * nxt.P + 4];
+                        }
+                        if (cur.g < totalTests) {
+                            const float4 ro = ws->ro[cur.o], rd = ws->rd[cur.o];
+                            float t, u, v;
+                            int at;
+                            // the better of the pair's two candidates below the ray's nearest (t >= 0; -0.0 keyed as +0.0)
+                            const unsigned k32 = pairCandidate(cur.q0, cur.q1, cur.q2, cur.q3, cur.q4, 2 * cur.P,
+                                                               makeRayP(F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z)), ro.w, t, u, v, at);
+                            if (k32 != 0xFFFFFFFFu) atomicMin(&ws->key[cur.o], ((unsigned long long)k32 << 32) | (unsigned)at);
+                        }
+                    };
+                    for (int base = 0; base < totalTests; base += 128) {
+                        round(ea, eb, base);
+                        if (base + 64 >= totalTests) break;
+                        round(eb, ea, base + 64);
+                    }
+                } else {
+                    // (RT_FLAG_WATERTIGHT: v0..v2 are the three vertices from the 128-byte records)
+                    const float4 *triData = reinterpret_cast<const float4 *>(sc.tris128);
+                    constexpr int triStride = 8;
+                    struct Pair { // entry g of the list: ray of rank o, triangle tri
+                        int g, o, tri;
+                        float4 v0, v1, v2;
+                    };
+                    Pair pa, pb;
+                    pa.g = lane, pa.o = 0, pa.tri = 0;
+                    pa.v0 = pa.v1 = pa.v2 = make_float4(0, 0, 0, 0);
+                    pb = pa;
+                    if (pa.g < totalTests) {
+                        pa.o = rankBase + __popcll(heads & atOrBelow);
+                        pa.tri = ws->first[pa.o] + pa.g;
+                        pa.v0 = triData[triStride * pa.tri];
+                        pa.v1 = triData[triStride * pa.tri + 1];
+                        pa.v2 = triData[triStride * pa.tri + 2];
+                    }
+                    auto round = [&](const Pair &cur, Pair &nxt, int base) {
+                        nxt.g = cur.g + 64;
+                        rankBase += __popcll(heads);
+                        if (base + 64 < totalTests) heads = ws->heads[(base >> 6) + 1];
+                        if (nxt.g < totalTests) {
+                            nxt.o = rankBase + __popcll(heads & atOrBelow);
+                            nxt.tri = ws->first[nxt.o] + nxt.g;
+                            nxt.v0 = triData[triStride * nxt.tri];
+                            nxt.v1 = triData[triStride * nxt.tri + 1];
+                            nxt.v2 = triData[triStride * nxt.tri + 2];
+                        }
+                        if (cur.g < totalTests) {
+                            const float4 ro = ws->ro[cur.o], rd = ws->rd[cur.o];
+                            float tn = ro.w, tt = 0.0f, tu = 0.0f, tv = 0.0f;
+                            int th = -1;
                             testTriangleWt(xyz(cur.v0), xyz(cur.v1), xyz(cur.v2), cur.tri, F3(ro.x, ro.y, ro.z),
                                            wtSetup(F3(rd.x, rd.y, rd.z)), tn, th, tt, tu, tv);
-                        else
-                            testTriangle<false>(cur.v0, cur.v1, cur.v2, cur.tri, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), tn,
-                                                th, tt, tu, tv);
-                        if (th >= 0) { // t >= 0 and t < the ray's nearest; -0.0 is keyed as +0.0
-                            const unsigned long long key =
-                                ((unsigned long long)__float_as_uint(tt + 0.0f) << 32) | (unsigned)cur.tri;
-                            atomicMin(&ws->key[cur.o], key);
+                            if (th >= 0) { // t >= 0 and t < the ray's nearest; -0.0 is keyed as +0.0
+                                const unsigned long long key =
+                                    ((unsigned long long)__float_as_uint(tt + 0.0f) << 32) | (unsigned)cur.tri;
+                                atomicMin(&ws->key[cur.o], key);
+                            }
                         }
+                    };
+                    for (int base = 0; base < totalTests; base += 128) {
+                        round(pa, pb, base);
+                        if (base + 64 >= totalTests) break;
+                        round(pb, pa, base + 64);
                     }
-                };
-                for (int base = 0; base < totalTests; base += 128) {
-                    round(pa, pb, base);
-                    if (base + 64 >= totalTests) break;
-                    round(pb, pa, base + 64);
                 }
                 if (lane * 64 < totalTests) ws->heads[lane] = 0ull; // leave the bit string clear for the next round
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -705,15 +754,20 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 if (cnt > 0) {
                     const unsigned long long key = ws->key[rank];
                     if (key != ~0ull) { // the owner repeats the winning test: same arithmetic, same t, u, v
-                        const int wtri = (int)(unsigned)(key & 0xFFFFFFFFull);
-                        if (WATERTIGHT)
-                            testTriangleWt(xyz(triData[8 * wtri]), xyz(triData[8 * wtri + 1]), xyz(triData[8 * wtri + 2]), wtri,
+                        const int won = (int)(unsigned)(key & 0xFFFFFFFFull);
+                        if constexpr (PAIRS) {
+                            // (the winner's pair, both halves in slot order from the ray's nearest: the pair's better
+                            // candidate IS the winner — a better one in the other half would have won instead)
+                            const int P = won >> 1;
+                            testPair(sc.triPairs[5 * P], sc.triPairs[5 * P + 1], sc.triPairs[5 * P + 2], sc.triPairs[5 * P + 3],
+                                     sc.triPairs[5 * P + 4], 2 * P, makeRayP(origin, dir), nearest, hitTri, hitT, hitU, hitV);
+                        } else {
+                            const float4 *triData = reinterpret_cast<const float4 *>(sc.tris128);
+                            testTriangleWt(xyz(triData[8 * won]), xyz(triData[8 * won + 1]), xyz(triData[8 * won + 2]), won,
                                            origin, wtSetup(dir), nearest, hitTri, hitT, hitU, hitV);
-                        else
-                            testTriangle<false>(sc.tris48[3 * wtri], sc.tris48[3 * wtri + 1], sc.tris48[3 * wtri + 2], wtri,
-                                                origin, dir, nearest, hitTri, hitT, hitU, hitV);
+                        }
                     }
-                    tests += (unsigned)cnt;
+                    tests += (unsigned)leafCount;
                 }
                 __builtin_amdgcn_wave_barrier();
                 WT(wtRetest += __any(cnt > 0 && ws->key[rank] != ~0ull) ? 1 : 0; wtFinish += clock64() - c4;)
@@ -722,8 +776,10 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
         WT(const long long c5 = clock64();)
         if (active && leafCount > 0) {
             if (!shared) { // every lane tests its own leaf, four triangles per batch of loads
-                if (WATERTIGHT)
+                if constexpr (WATERTIGHT)
                     testLeafWt(sc.tris128, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+                else if constexpr (PAIRS)
+                    testLeafPairs(sc.triPairs, leafFirst, leafCount, makeRayP(origin, dir), nearest, hitTri, hitT, hitU, hitV);
                 else
                     testLeaf<false>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
                 tests += (unsigned)leafCount;
@@ -731,6 +787,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             if (bounded && hitTri >= 0) next = -1; // any hit nearer than the light settles a shadow ray
         } else if (active && next == -1) {
             // the walk is over: publish the closest hit and free the lane
+            if (PAIRS && hitTri >= 0) hitTri = sc.slotTri[hitTri]; // slot of the pair stream -> triangle index
             if (bounded && hitTri < 0) hitTri = WF_HIT_UNBLOCKED;
             wf.rayHit[slot] = make_int4(hitTri, __float_as_int(hitT), __float_as_int(hitU), __float_as_int(hitV));
             if (wantWork) wf.rayWork[slot] = make_int2(iterations, (int)tests);
@@ -965,46 +1022,26 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
 
         // ---- leaf: 16 triangles per step across the row, closest accepted hit by row reduction
         WT(const long long c2 = clock64(); wtWalkC += c2 - c1; wtLeaves += __any(active && leafCount > 0) ? 1 : 0;)
-        RT_WALK_CHECK(!(active && leafCount > 0) || (leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numTris), 1,
+        RT_WALK_CHECK(!(active && leafCount > 0) || (leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numSlots), 1,
                       { leafCount = 0; next = -1; });
         if (active && leafCount > 0) {
-            const int i0 = leafFirst + rowLane, i1 = i0 + 16;
-            const bool has0 = rowLane < leafCount, has1 = rowLane + 16 < leafCount;
-            float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, d0 = a0, d1 = a0, d2 = a0;
-            if (has0) {
-                a0 = sc.tris48[3 * i0];
-                a1 = sc.tris48[3 * i0 + 1];
-                a2 = sc.tris48[3 * i0 + 2];
-            }
-            if (has1) {
-                d0 = sc.tris48[3 * i1];
-                d1 = sc.tris48[3 * i1 + 1];
-                d2 = sc.tris48[3 * i1 + 2];
+            // lane j: the pair record of slots leafFirst + 2j and + 2j + 1 (trace3_device.h: pairCandidate) — a leaf of up to
+            // 32 triangles in ONE step of the row, both triangles of a lane on packed fp32
+            const int P = (leafFirst >> 1) + rowLane;
+            const bool has = 2 * rowLane < leafCount;
+            float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
+            if (has) {
+                q0 = sc.triPairs[5 * P];
+                q1 = sc.triPairs[5 * P + 1];
+                q2 = sc.triPairs[5 * P + 2];
+                q3 = sc.triPairs[5 * P + 3];
+                q4 = sc.triPairs[5 * P + 4];
             }
             WT(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long cl = clock64(); wtLoad += cl - c2;)
             unsigned bestKey = 0xFFFFFFFFu;
             float bestT = 0.0f, bestU = 0.0f, bestV = 0.0f;
             int bestI = 0x7FFFFFFF;
-            float t, u, v;
-            if (has0 && triangleCandidate(a0, a1, a2, origin, dir, nearest, t, u, v)) {
-                bestKey = __float_as_uint(t + 0.0f); // -0.0 is keyed as +0.0
-                bestT = t;
-                bestU = u;
-                bestV = v;
-                bestI = i0;
-            }
-            if (__any(has1)) { // (leaves of more than 16 triangles)
-                if (has1 && triangleCandidate(d0, d1, d2, origin, dir, nearest, t, u, v)) {
-                    const unsigned key = __float_as_uint(t + 0.0f);
-                    if (key < bestKey) { // strict: on equal t the lower index (i0) stays
-                        bestKey = key;
-                        bestT = t;
-                        bestU = u;
-                        bestV = v;
-                        bestI = i1;
-                    }
-                }
-            }
+            if (has) bestKey = pairCandidate(q0, q1, q2, q3, q4, 2 * P, makeRayP(origin, dir), nearest, bestT, bestU, bestV, bestI);
             WT(const long long ct = clock64(); wtTest += ct - cl;)
             // smallest t of the row; among equal t the smallest index (trace3.cs:177 keeps the first)
             const unsigned minKey = rowMinU32(bestKey);
@@ -1025,7 +1062,8 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
         WT(const long long c3 = clock64(); wtLeaf += c3 - c2;)
         if (active && next == -1) {
             if (rowLane == 0) {
-                const int tri = (bounded && hitTri < 0) ? WF_HIT_UNBLOCKED : hitTri;
+                // (hitTri is a slot of the pair stream: the triangle's index in the uploaded stream is looked up here)
+                const int tri = hitTri >= 0 ? sc.slotTri[hitTri] : (bounded ? WF_HIT_UNBLOCKED : hitTri);
                 wf.rayHit[slot] = make_int4(tri, __float_as_int(hitT), __float_as_int(hitU), __float_as_int(hitV));
                 if (wantWork) wf.rayWork[slot] = make_int2(iterations, (int)tests);
                 cRays++;
@@ -1132,6 +1170,44 @@ __global__ __launch_bounds__(256) void rt_wf_blend_kernel(RtImages img, WfParams
             wf.flat.pos[cell] = ps;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ pair stream
+// One thread per node: a leaf's {v0, e1, e2} records, two triangles per 80-byte record, interleaved component by
+// component (trace3_device.h: testPair), written at the slots its packed node record names; slotTri maps back.
+__global__ __launch_bounds__(256) void rt_build_pairs_kernel(const float4 *__restrict__ boxes, const int2 *__restrict__ leaves,
+                                                             int numNodes, const float4 *__restrict__ tris48,
+                                                             float4 *__restrict__ pairs, int *__restrict__ slotTri,
+                                                             int numSlots) {
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node >= numNodes) return;
+    const int2 lr = leaves[node];
+    if (lr.y <= 0) return;
+    const int s0 = __float_as_int(boxes[2 * node + 1].w) & 0x03FFFFFF;
+    for (int k = 0; k < lr.y; k += 2) {
+        if (s0 + k + 1 >= numSlots) return; // (cannot happen: the host sized the stream from the same records)
+        const int ia = lr.x + k;
+        const bool hasB = k + 1 < lr.y;
+        const float4 z = make_float4(0, 0, 0, 0);
+        const float4 a0 = tris48[3 * ia], a1 = tris48[3 * ia + 1], a2 = tris48[3 * ia + 2];
+        const float4 b0 = hasB ? tris48[3 * ia + 3] : z, b1 = hasB ? tris48[3 * ia + 4] : z, b2 = hasB ? tris48[3 * ia + 5] : z;
+        float4 *out = pairs + (size_t)5 * ((s0 + k) >> 1);
+        out[0] = make_float4(a0.x, b0.x, a0.y, b0.y);
+        out[1] = make_float4(a0.z, b0.z, a1.x, b1.x);
+        out[2] = make_float4(a1.y, b1.y, a1.z, b1.z);
+        out[3] = make_float4(a2.x, b2.x, a2.y, b2.y);
+        out[4] = make_float4(a2.z, b2.z, 0.0f, 0.0f);
+        slotTri[s0 + k] = ia;
+        slotTri[s0 + k + 1] = hasB ? ia + 1 : -1;
+    }
+}
+
+hipError_t rtLaunchBuildPairs(const float4 *boxes, const int2 *leaves, int numNodes, const float4 *tris48, float4 *pairs,
+                              int *slotTri, int numSlots, hipStream_t stream) {
+    if (numNodes <= 0 || numSlots <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_build_pairs_kernel, dim3((numNodes + 255) / 256), dim3(256), 0, stream, boxes, leaves, numNodes, tris48,
+                       pairs, slotTri, numSlots);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------ host
