@@ -39,7 +39,7 @@ struct rt_ctx {
     bool cellsStale = true;
     DevBuf spec;          // decision-tree table of the row-mode walk (RtScene::spec); hasSpec says whether it is valid
     bool hasSpec = false;
-    DevBuf triPairs, slotTri; // packed scenes: the leaves' triangles as pair records + slot -> triangle (RtScene::triPairs)
+    DevBuf triPairs, boxesP, slotTri; // packed scenes: the leaves' triangles as pair records + slot -> triangle (RtScene::triPairs)
     int numSlots = 0;         // slots the packed node records address (every leaf starts at an even slot)
     bool pairsValid = false;  // triPairs / slotTri hold the uploaded nodes' leaves of the uploaded triangles
     int numNodes = 0, numTris = 0, numMtls = 0, numEmitters = 0;
@@ -107,6 +107,7 @@ struct rt_ctx {
     int tuneMinRays = 4;                             // RT_WF_MIN_RAYS: floor of the rays-per-wave rule
     int tuneCoopA = 6, tuneCoopB = 0;                // RT_WF_COOP_A / _B: the per-round rule of WfParams::coopA
     int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 0, tuneChunk = 64;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
+    int tunePairs = -1;                              // RT_WF_PAIRS (WfParams::extendPairs)
     int tuneLongWalk = 0;                            // RT_WF_LONG_WALK (WfParams::longWalk)
     int tuneRowStaticK = 8, tuneRowChunkDiv = 2;     // RT_WF_ROW_STATIC, RT_WF_ROW_CHUNK_DIV (WfParams::rowStaticK / rowChunkDiv)
     int tuneRowMode = -1, tuneRowMaxRays = -1;       // RT_WF_ROWS (0 never, 1 always, 2 per stage by ray count), RT_WF_ROW_MAX_RAYS

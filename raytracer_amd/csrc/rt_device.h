@@ -4,7 +4,7 @@
 //   boxes   float4[2*N]   node i → {min.xyz, bits(w0)}, {max.xyz, bits(w1)}                 32 B, 32-B aligned
 //           packed form (every leaf has <= 32 triangles and the triangle stream < 2^26 records, true for any tree
 //           the reference's builder makes up to 67 M triangles): w0 = missNext; w1 = hitNext for an inner node,
-//           0x80000000 | (numTris-1) << 26 | firstSlot for a leaf (whose hitNext equals its missNext), so that one
+//           0x80000000 | (numTris-1) << 26 | firstTri for a leaf (whose hitNext equals its missNext), so that one
 //           32-byte read gives the box, both links and the leaf range;
 //           plain form (anything else): w0 = hitNext, w1 = missNext, leaf range from `leaves`
 //   leaves  int2[N]       node i → {firstTri, numTris}                                    8 B
@@ -72,10 +72,12 @@ struct RtScene {
     // at once), 15..30: the nodes the walk can stand on after four decisions; 0xFFFF = the walk has ended there.
     // Entry 0: bit p set = position p (0..14) has a node; entry 31: bit p set = that node is a leaf.
     const uint16_t *spec;
-    // Packed scenes only (trace3_device.h: testPair): the leaves' triangles as 80-byte PAIR records {v0, e1, e2 of slots
-    // 2P and 2P+1, component by component}, every leaf starting at an even slot (a packed leaf word holds its first
-    // slot), and the triangle index of every slot (-1: the padding half of a leaf of odd size).
+    // Packed scenes only (trace3_device.h: testPair), read by the PAIRS variant of the extend kernel: the leaves'
+    // triangles as 80-byte PAIR records {v0, e1, e2 of slots 2P and 2P+1, component by component}, every leaf starting
+    // at an even slot; the triangle index of every slot (-1: the padding half of a leaf of odd size); and a second set
+    // of packed node records, equal to `boxes` except that a leaf word holds the leaf's first SLOT.
     const float4 *triPairs;
+    const float4 *boxesP;
     const int *slotTri;
     int numSlots;
 };

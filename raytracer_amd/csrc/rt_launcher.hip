@@ -31,7 +31,7 @@ hipError_t rtLaunchTonemap(const float4 *colorF32, const uint2 *colorF16, uint32
 hipError_t rtLaunchFlatLevels(const RtFlatCells &rec, uint8_t *level, uint2 *texels, int W, int H, int passes,
                               const float *c_phi, const float *n_phi, const float *p_phi, hipStream_t stream);
 int rtAtrousMaxStep();
-hipError_t rtLaunchBuildPairs(const float4 *boxes, const int2 *leaves, int numNodes, const float4 *tris48, float4 *pairs,
+hipError_t rtLaunchBuildPairs(const float4 *boxesP, const int2 *leaves, int numNodes, const float4 *tris48, float4 *pairs,
                               int *slotTri, int numSlots, hipStream_t stream); // wavefront.hip
 // rt_comm.hip
 void rtCommQuiesce(rt_ctx *c);
@@ -196,15 +196,15 @@ void rtMarkKernel(void *opaque, int kind, bool begin) {
 // gets none; such a scene is refused at launch anyway (RT_ECORRUPT).
 static int rebuildPairs(rt_ctx *c) {
     c->pairsValid = false;
-    if (c->packedLeaves && c->boxes.p && c->numSlots <= 0) { // a tree without leaves: nothing to pair, nothing is ever read
+    if (c->packedLeaves && c->boxesP.p && c->numSlots <= 0) { // a tree without leaves: nothing to pair, nothing is ever read
         c->pairsValid = true;
         return RT_OK;
     }
-    if (!c->packedLeaves || !c->boxes.p || !c->tris48.p || c->maxTriEnd > c->numTris) return RT_OK;
+    if (!c->packedLeaves || !c->boxesP.p || !c->tris48.p || c->maxTriEnd > c->numTris) return RT_OK;
     int r;
     if ((r = ensure(c, c->triPairs, (size_t)(c->numSlots / 2) * 80)) || (r = ensure(c, c->slotTri, (size_t)c->numSlots * 4)))
         return r;
-    hipError_t e = rtLaunchBuildPairs((const float4 *)c->boxes.p, (const int2 *)c->leaves.p, c->numNodes,
+    hipError_t e = rtLaunchBuildPairs((const float4 *)c->boxesP.p, (const int2 *)c->leaves.p, c->numNodes,
                                       (const float4 *)c->tris48.p, (float4 *)c->triPairs.p, (int *)c->slotTri.p,
                                       c->numSlots, c->stream);
     if (e != hipSuccess) return hipFail(c, e, "pair stream build");
@@ -332,6 +332,7 @@ int rt_create(int device_id, rt_ctx **out) {
     if (const char *e = std::getenv("RT_WF_FILL")) c->tuneFill = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_ROWS")) c->tuneRowMode = std::max(0, std::min(2, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_ROW_MAX_RAYS")) c->tuneRowMaxRays = std::max(0, std::atoi(e));
+    if (const char *e = std::getenv("RT_WF_PAIRS")) c->tunePairs = std::max(-1, std::min(1, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_LONG_WALK")) c->tuneLongWalk = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("RT_WF_ROW_STATIC")) c->tuneRowStaticK = std::max(0, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_ROW_CHUNK_DIV")) c->tuneRowChunkDiv = std::max(1, std::min(64, std::atoi(e)));
@@ -371,7 +372,7 @@ void rt_destroy(rt_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     DevBuf *all[] = {&c->boxes, &c->leaves, &c->tris48, &c->tris128, &c->mtls, &c->emitters, &c->color, &c->normal,
                      &c->pos, &c->filt[0], &c->filt[1], &c->tridx, &c->visits, &c->stats, &c->ldr, &c->counters,
-                     &c->spec, &c->triPairs, &c->slotTri, &c->flatFlag, &c->flatColor, &c->flatNormal, &c->flatPos, &c->flatLevel, &c->flatTexels};
+                     &c->spec, &c->triPairs, &c->boxesP, &c->slotTri, &c->flatFlag, &c->flatColor, &c->flatNormal, &c->flatPos, &c->flatLevel, &c->flatTexels};
     for (rt_ctx::Lane &L : c->lane) {
         for (DevBuf &b : L.wfState) releaseBuf(b);
         for (DevBuf &b : L.wfRay) releaseBuf(b);
@@ -444,7 +445,8 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
         long long totalSlots = 0;
         for (size_t i = 0; i < n; ++i)
             if (src[i].numTris > 0) totalSlots += ((long long)src[i].numTris + 1) & ~1ll;
-        const bool packed = leafLinksEqual && !innerEndsWalk && maxLeaf <= 32 && totalSlots <= (1ll << 26);
+        const bool packed = leafLinksEqual && !innerEndsWalk && maxLeaf <= 32 && maxEnd <= (1ll << 26) && totalSlots <= (1ll << 26);
+        std::vector<float4> boxesP(packed ? 2 * n : 0);
         maxEnd = 0;
         long long slotAt = 0;
         for (size_t i = 0; i < n; ++i) {
@@ -455,9 +457,11 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
                 return fail(c, RT_ECORRUPT, "rt_upload: negative triangle range at node " + std::to_string(i));
             if (s.numTris > 0 && (long long)s.firstTri + s.numTris > maxEnd) maxEnd = (long long)s.firstTri + s.numTris;
             int w0 = s.hitNext, w1 = s.missNext;
+            int w1p = 0; // the leaf word of the PAIRS kernel's records: first slot of the pair stream instead of first triangle
             if (packed) {
                 w0 = s.missNext;
-                w1 = s.numTris > 0 ? (int)(0x80000000u | ((unsigned)(s.numTris - 1) << 26) | (unsigned)slotAt) : s.hitNext;
+                w1 = s.numTris > 0 ? (int)(0x80000000u | ((unsigned)(s.numTris - 1) << 26) | (unsigned)s.firstTri) : s.hitNext;
+                w1p = s.numTris > 0 ? (int)(0x80000000u | ((unsigned)(s.numTris - 1) << 26) | (unsigned)slotAt) : s.hitNext;
                 if (s.numTris > 0) slotAt += ((long long)s.numTris + 1) & ~1ll;
             }
             float hb, mb;
@@ -465,6 +469,11 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
             std::memcpy(&mb, &w1, 4);
             boxes[2 * i] = make_float4(s.min[0], s.min[1], s.min[2], hb);
             boxes[2 * i + 1] = make_float4(s.max[0], s.max[1], s.max[2], mb);
+            if (packed) {
+                std::memcpy(&mb, &w1p, 4);
+                boxesP[2 * i] = boxes[2 * i];
+                boxesP[2 * i + 1] = make_float4(s.max[0], s.max[1], s.max[2], mb);
+            }
             leaves[i] = make_int2(s.firstTri, s.numTris);
         }
         if (maxEnd > 0x7FFFFFFF) return fail(c, RT_ECORRUPT, "rt_upload: triangle range overflow");
@@ -499,6 +508,7 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
             c->hasSpec = true;
         }
         if ((r = uploadTo(c, c->boxes, boxes.data(), boxes.size() * sizeof(float4)))) return r;
+        if (packed && (r = uploadTo(c, c->boxesP, boxesP.data(), boxesP.size() * sizeof(float4)))) return r;
         if ((r = uploadTo(c, c->leaves, leaves.data(), leaves.size() * sizeof(int2)))) return r;
         c->numNodes = (int)n;
         c->maxTriEnd = (int)maxEnd;
@@ -641,6 +651,7 @@ void fillScene(const rt_ctx *c, RtScene &sc, RtImages &img) {
     sc.packedLeaves = c->packedLeaves ? 1 : 0;
     sc.spec = c->hasSpec ? (const uint16_t *)c->spec.p : nullptr;
     sc.triPairs = (const float4 *)c->triPairs.p;
+    sc.boxesP = c->pairsValid ? (const float4 *)c->boxesP.p : nullptr;
     sc.slotTri = (const int *)c->slotTri.p;
     sc.numSlots = c->numSlots;
     img.color = (float4 *)c->color.p;
@@ -746,6 +757,7 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     wp.rowMode = c->tuneRowMode >= 0 ? c->tuneRowMode : 2;
     wp.rowMaxRays = c->tuneRowMaxRays >= 0 ? c->tuneRowMaxRays : 65536;
     wp.longWalk = c->tuneLongWalk;
+    wp.extendPairs = c->tunePairs;
     wp.rowStaticK = c->tuneRowStaticK;
     wp.rowChunkDiv = c->tuneRowChunkDiv;
     wp.extendCacheNodes = c->tuneCacheNodes;
@@ -885,7 +897,6 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
         if (c->maxTriEnd > c->numTris)
             return fail(c, RT_ECORRUPT, "rt_trace: a leaf references triangles beyond the uploaded triangle stream");
-        if (c->packedLeaves && !c->pairsValid) return fail(c, RT_ESTATE, "rt_trace: the scene's pair stream is missing (upload failed?)");
         RtScene sc;
         RtImages img;
         fillScene(c, sc, img);
@@ -973,7 +984,6 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
         if (c->maxTriEnd > c->numTris)
             return fail(c, RT_ECORRUPT, "rt_trace: a leaf references triangles beyond the uploaded triangle stream");
-        if (c->packedLeaves && !c->pairsValid) return fail(c, RT_ESTATE, "rt_trace: the scene's pair stream is missing (upload failed?)");
         for (int slot = RT_SLOT_VORONOI_NORMALS; slot <= RT_SLOT_QVISITS; ++slot)
             if (!c->raw[slot].p) return fail(c, RT_ESTATE, "rt_trace: the Q-table kernel needs slots 7..10 uploaded");
         if (p->numPoints <= 0 || p->maxTheta <= 0 || p->maxPhi <= 0 ||
@@ -1091,7 +1101,6 @@ int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const
         return fail(c, RT_ESTATE, "rt_trace_batch_static: nodes, triangles and materials must be uploaded first");
     if (c->maxTriEnd > c->numTris)
         return fail(c, RT_ECORRUPT, "rt_trace_batch_static: a leaf references triangles beyond the uploaded triangle stream");
-    if (c->packedLeaves && !c->pairsValid) return fail(c, RT_ESTATE, "rt_trace_batch_static: the scene's pair stream is missing (upload failed?)");
     const size_t tilePixels = (size_t)(r.x1 - r.x0) * (size_t)(r.y1 - r.y0);
     if (tilePixels * (size_t)n > (size_t)RT_STATIC_MAX_PATHS)
         return fail(c, RT_EINVAL, "rt_trace_batch_static: tile pixels x samples = " + std::to_string(tilePixels * (size_t)n) +

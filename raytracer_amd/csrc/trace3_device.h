@@ -239,8 +239,9 @@ __device__ __forceinline__ void testLeaf(const float4 *__restrict__ tris48, int 
 }
 
 // ---------------------------------------------------------------- two triangles per test (packed fp32)
-// For packed scenes the launcher keeps the leaves' triangles a second time as PAIRS (rt_launcher.hip: rtBuildPairs):
-// every leaf starts at an even "slot", slots 2P and 2P+1 share one 80-byte record
+// For packed scenes the launcher keeps the leaves' triangles a second time as PAIRS (rt_launcher.hip: rebuildPairs),
+// with node records of their own whose leaf words address it (RtScene::boxesP): every leaf starts at an even "slot",
+// slots 2P and 2P+1 share one 80-byte record
 //   q0 = {v0.x_a, v0.x_b, v0.y_a, v0.y_b}  q1 = {v0.z_a, v0.z_b, e1.x_a, e1.x_b}  q2 = {e1.y_a, e1.y_b, e1.z_a, e1.z_b}
 //   q3 = {e2.x_a, e2.x_b, e2.y_a, e2.y_b}  q4 = {e2.z_a, e2.z_b, 0, 0}
 // (a leaf of odd size ends with an all-zero half: det = 0 and t = 0 * inf = NaN, which `t >= 0` never accepts), and
@@ -445,9 +446,9 @@ __device__ __forceinline__ void testLeafWt(const RtTri128 *__restrict__ tris, in
 // the chain gets several times shorter; for large scenes the cached prefix is the top of the tree.
 extern __shared__ float4 rtLdsNodes[];
 
-__device__ __forceinline__ void fillNodeCache(const RtScene &sc) {
+__device__ __forceinline__ void fillNodeCache(const RtScene &sc, const float4 *nodeRecs) {
     const int m = sc.cacheNodes;
-    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) rtLdsNodes[i] = sc.boxes[i];
+    for (int i = threadIdx.x; i < 2 * m; i += blockDim.x) rtLdsNodes[i] = nodeRecs[i];
     __syncthreads();
 }
 struct NodeLinks {
@@ -529,7 +530,6 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
     hit.t = hit.u = hit.v = 0.0f;
     bool ok = true;
     const bool ltx = invdir.x < 0.0f, lty = invdir.y < 0.0f, ltz = invdir.z < 0.0f;
-    const RayP rayP = makeRayP(origin, dir);
     for (;;) {
         int leafFirst = 0, leafCount = 0;
         if constexpr (NODES == NODES_PLAIN) {
@@ -603,25 +603,13 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
             leafCount = leafWord != 0 ? ((leafWord >> 26) & 31) + 1 : 0;
         }
         if (leafCount <= 0) break;
-        if constexpr (NODES == NODES_PLAIN) { // leaf ranges are triangle indices
-            RT_WALK_CHECK(leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numTris, 1, { next = -1; break; });
-            if (WATERTIGHT)
-                testLeafWt(sc.tris128, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
-            else
-                testLeaf<true>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
-        } else { // packed records: leaf ranges are slots of the pair stream
-            RT_WALK_CHECK(leafFirst >= 0 && !(leafFirst & 1) && (long long)leafFirst + leafCount <= (long long)sc.numSlots, 1,
-                          { next = -1; break; });
-            if (WATERTIGHT) { // (the watertight test reads the 128-byte records: back to triangle indices)
-                const int firstTri = sc.slotTri[leafFirst];
-                testLeafWt(sc.tris128, firstTri, firstTri + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
-            } else {
-                testLeafPairs(sc.triPairs, leafFirst, leafCount, rayP, nearest, hit.tridx, hit.t, hit.u, hit.v);
-            }
-        }
+        RT_WALK_CHECK(leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numTris, 1, { next = -1; break; });
+        if (WATERTIGHT)
+            testLeafWt(sc.tris128, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
+        else
+            testLeaf<true>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
         tests += (unsigned)leafCount;
     }
-    if (NODES != NODES_PLAIN && !WATERTIGHT && hit.tridx >= 0) hit.tridx = sc.slotTri[hit.tridx];
     c.lastIterations = iterations;
     c.rays++;
     c.visits += (unsigned)iterations;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
     c.rays = c.visits = c.tests = c.shaded = 0;
     c.lastIterations = 0;
     unsigned primaryVisits = 0, primaryTests = 0;
-    fillNodeCache(sc); // the top of the tree (all of it for the named scenes) in LDS: trace3_device.h, loadNodeT
+    fillNodeCache(sc, sc.boxes); // the top of the tree (all of it for the named scenes) in LDS: trace3_device.h, loadNodeT
 
     if (active) {
         const int W = img.width, H = img.height;

@@ -391,7 +391,12 @@ struct WaveShare { // phase-2 exchange area of one wave (3 KB); first/ro/rd/key 
     unsigned long long key[64];   // closest accepted hit so far: (bits(t), triangle)
 };
 
-template <int NODES, bool WATERTIGHT>
+// PAIRS: leaves are tested two triangles at a time on packed fp32 from the pair stream (trace3_device.h: testPair).
+// Measured on MI355X (scripts/micro/pk_rate.hip): a v_pk_mul_f32 / v_pk_add_f32 occupies the issue slot
+// 1.7 times as long as its scalar form, so the packed test buys at most 1.19x in arithmetic throughput and lengthens
+// every dependent chain; room.obj did not change, the metric frame lost 10 %.  What it does buy is bytes (40 per
+// triangle instead of 48), so the launcher uses it for scenes beyond the L2s (config #5: -7.5 %) and nowhere else.
+template <int NODES, bool WATERTIGHT, bool PAIRS>
 __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams p, WfBuffers wf, int stage,
                                                            int refillLanes, RtCountersDev *counters) {
     const int n = min(wf.counts[stage], wf.capacity);
@@ -419,7 +424,8 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
     const int coopMode = NODES == NODES_PLAIN ? 0 : raysPerWave < 64 ? 1 : p.extendCoop;
     const int walkStop = coopMode == 0 ? 8 : p.walkStop; // see phase 1
     const bool rayLane = lane < raysPerWave;
-    fillNodeCache(sc);
+    const float4 *nodeRecs = PAIRS ? sc.boxesP : sc.boxes; // (the PAIRS kernel's leaf words address the pair stream)
+    fillNodeCache(sc, nodeRecs);
     // per-wave scratch behind the node cache
     WaveShare *ws = reinterpret_cast<WaveShare *>(rtLdsNodes + 2 * sc.cacheNodes) + (threadIdx.x >> 6);
     if (lane < 32) ws->heads[lane] = 0ull;
@@ -572,8 +578,8 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                     b0 = rtLdsNodes[2 * next];
                     b1 = rtLdsNodes[2 * next + 1];
                 } else {
-                    b0 = sc.boxes[2 * next];
-                    b1 = sc.boxes[2 * next + 1];
+                    b0 = nodeRecs[2 * next];
+                    b1 = nodeRecs[2 * next + 1];
                 }
                 const int w0 = __float_as_int(b0.w), w1 = __float_as_int(b1.w);
                 const float m1x = (b0.x - origin.x) * invdir.x, m1y = (b0.y - origin.y) * invdir.y,
@@ -603,13 +609,13 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             for (int o = 32; o; o >>= 1) d = max(d, __shfl_xor(d, o, 64));
             wtWalk += d;
         } const long long c2 = clock64(); wtWalkC += c2 - c1;)
-        // Leaf ranges: triangle indices for plain records, SLOTS of the pair stream for packed ones (rt_device.h).  The
-        // (opt-in) watertight test reads the 128-byte triangle records, so it translates the range back first.
-        constexpr bool PAIRS = NODES != NODES_PLAIN && !WATERTIGHT; // this kernel tests two triangles at a time
+        // Leaf ranges are triangle indices — except in the PAIRS kernel, which walks the second set of node records
+        // (RtScene::boxesP) whose leaf words hold SLOTS of the pair stream (rt_device.h).
+        static_assert(!PAIRS || (NODES != NODES_PLAIN && !WATERTIGHT), "the pair stream exists for packed scenes, plain test");
+        constexpr bool SLOTS = PAIRS; // leaf ranges and hitTri are slots of the pair stream: translated when the hit is published
         RT_WALK_CHECK(!(active && leafCount > 0) ||
-                          (leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)(NODES == NODES_PLAIN ? sc.numTris : sc.numSlots)),
+                          (leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)(PAIRS ? sc.numSlots : sc.numTris)),
                       1, { leafCount = 0; next = -1; });
-        if (NODES != NODES_PLAIN && WATERTIGHT && active && leafCount > 0) leafFirst = sc.slotTri[leafFirst];
         // phase 2: the leaves' triangles (geometry.glsl:31-51, trace3.cs:172-186), shared out over the wave.
         // Lanes hold leaves of 1..32 triangles (or none); testing "my leaf" lane by lane leaves most lanes idle
         // (measured: 38 % of the lanes active on room.obj, 20 % on scene.obj, and the kernel is VALU-issue
@@ -698,9 +704,9 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                         round(eb, ea, base + 64);
                     }
                 } else {
-                    // (RT_FLAG_WATERTIGHT: v0..v2 are the three vertices from the 128-byte records)
-                    const float4 *triData = reinterpret_cast<const float4 *>(sc.tris128);
-                    constexpr int triStride = 8;
+                    // (RT_FLAG_WATERTIGHT: v0..v2 are the three vertices from the 128-byte records instead of {v0, e1, e2})
+                    const float4 *triData = WATERTIGHT ? reinterpret_cast<const float4 *>(sc.tris128) : sc.tris48;
+                    constexpr int triStride = WATERTIGHT ? 8 : 3;
                     struct Pair { // entry g of the list: ray of rank o, triangle tri
                         int g, o, tri;
                         float4 v0, v1, v2;
@@ -731,8 +737,12 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                             const float4 ro = ws->ro[cur.o], rd = ws->rd[cur.o];
                             float tn = ro.w, tt = 0.0f, tu = 0.0f, tv = 0.0f;
                             int th = -1;
-                            testTriangleWt(xyz(cur.v0), xyz(cur.v1), xyz(cur.v2), cur.tri, F3(ro.x, ro.y, ro.z),
-                                           wtSetup(F3(rd.x, rd.y, rd.z)), tn, th, tt, tu, tv);
+                            if (WATERTIGHT)
+                                testTriangleWt(xyz(cur.v0), xyz(cur.v1), xyz(cur.v2), cur.tri, F3(ro.x, ro.y, ro.z),
+                                               wtSetup(F3(rd.x, rd.y, rd.z)), tn, th, tt, tu, tv);
+                            else
+                                testTriangle<false>(cur.v0, cur.v1, cur.v2, cur.tri, F3(ro.x, ro.y, ro.z), F3(rd.x, rd.y, rd.z), tn,
+                                                    th, tt, tu, tv);
                             if (th >= 0) { // t >= 0 and t < the ray's nearest; -0.0 is keyed as +0.0
                                 const unsigned long long key =
                                     ((unsigned long long)__float_as_uint(tt + 0.0f) << 32) | (unsigned)cur.tri;
@@ -761,10 +771,13 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                             const int P = won >> 1;
                             testPair(sc.triPairs[5 * P], sc.triPairs[5 * P + 1], sc.triPairs[5 * P + 2], sc.triPairs[5 * P + 3],
                                      sc.triPairs[5 * P + 4], 2 * P, makeRayP(origin, dir), nearest, hitTri, hitT, hitU, hitV);
-                        } else {
+                        } else if constexpr (WATERTIGHT) {
                             const float4 *triData = reinterpret_cast<const float4 *>(sc.tris128);
                             testTriangleWt(xyz(triData[8 * won]), xyz(triData[8 * won + 1]), xyz(triData[8 * won + 2]), won,
                                            origin, wtSetup(dir), nearest, hitTri, hitT, hitU, hitV);
+                        } else {
+                            testTriangle<false>(sc.tris48[3 * won], sc.tris48[3 * won + 1], sc.tris48[3 * won + 2], won, origin, dir,
+                                                nearest, hitTri, hitT, hitU, hitV);
                         }
                     }
                     tests += (unsigned)leafCount;
@@ -787,7 +800,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
             if (bounded && hitTri >= 0) next = -1; // any hit nearer than the light settles a shadow ray
         } else if (active && next == -1) {
             // the walk is over: publish the closest hit and free the lane
-            if (PAIRS && hitTri >= 0) hitTri = sc.slotTri[hitTri]; // slot of the pair stream -> triangle index
+            if (SLOTS && hitTri >= 0) hitTri = sc.slotTri[hitTri]; // slot -> triangle index of the uploaded stream
             if (bounded && hitTri < 0) hitTri = WF_HIT_UNBLOCKED;
             wf.rayHit[slot] = make_int4(hitTri, __float_as_int(hitT), __float_as_int(hitU), __float_as_int(hitV));
             if (wantWork) wf.rayWork[slot] = make_int2(iterations, (int)tests);
@@ -1022,26 +1035,46 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
 
         // ---- leaf: 16 triangles per step across the row, closest accepted hit by row reduction
         WT(const long long c2 = clock64(); wtWalkC += c2 - c1; wtLeaves += __any(active && leafCount > 0) ? 1 : 0;)
-        RT_WALK_CHECK(!(active && leafCount > 0) || (leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numSlots), 1,
+        RT_WALK_CHECK(!(active && leafCount > 0) || (leafFirst >= 0 && (long long)leafFirst + leafCount <= (long long)sc.numTris), 1,
                       { leafCount = 0; next = -1; });
         if (active && leafCount > 0) {
-            // lane j: the pair record of slots leafFirst + 2j and + 2j + 1 (trace3_device.h: pairCandidate) — a leaf of up to
-            // 32 triangles in ONE step of the row, both triangles of a lane on packed fp32
-            const int P = (leafFirst >> 1) + rowLane;
-            const bool has = 2 * rowLane < leafCount;
-            float4 q0 = make_float4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0;
-            if (has) {
-                q0 = sc.triPairs[5 * P];
-                q1 = sc.triPairs[5 * P + 1];
-                q2 = sc.triPairs[5 * P + 2];
-                q3 = sc.triPairs[5 * P + 3];
-                q4 = sc.triPairs[5 * P + 4];
+            const int i0 = leafFirst + rowLane, i1 = i0 + 16;
+            const bool has0 = rowLane < leafCount, has1 = rowLane + 16 < leafCount;
+            float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, d0 = a0, d1 = a0, d2 = a0;
+            if (has0) {
+                a0 = sc.tris48[3 * i0];
+                a1 = sc.tris48[3 * i0 + 1];
+                a2 = sc.tris48[3 * i0 + 2];
+            }
+            if (has1) {
+                d0 = sc.tris48[3 * i1];
+                d1 = sc.tris48[3 * i1 + 1];
+                d2 = sc.tris48[3 * i1 + 2];
             }
             WT(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long cl = clock64(); wtLoad += cl - c2;)
             unsigned bestKey = 0xFFFFFFFFu;
             float bestT = 0.0f, bestU = 0.0f, bestV = 0.0f;
             int bestI = 0x7FFFFFFF;
-            if (has) bestKey = pairCandidate(q0, q1, q2, q3, q4, 2 * P, makeRayP(origin, dir), nearest, bestT, bestU, bestV, bestI);
+            float t, u, v;
+            if (has0 && triangleCandidate(a0, a1, a2, origin, dir, nearest, t, u, v)) {
+                bestKey = __float_as_uint(t + 0.0f); // -0.0 is keyed as +0.0
+                bestT = t;
+                bestU = u;
+                bestV = v;
+                bestI = i0;
+            }
+            if (__any(has1)) { // (leaves of more than 16 triangles)
+                if (has1 && triangleCandidate(d0, d1, d2, origin, dir, nearest, t, u, v)) {
+                    const unsigned key = __float_as_uint(t + 0.0f);
+                    if (key < bestKey) { // strict: on equal t the lower index (i0) stays
+                        bestKey = key;
+                        bestT = t;
+                        bestU = u;
+                        bestV = v;
+                        bestI = i1;
+                    }
+                }
+            }
             WT(const long long ct = clock64(); wtTest += ct - cl;)
             // smallest t of the row; among equal t the smallest index (trace3.cs:177 keeps the first)
             const unsigned minKey = rowMinU32(bestKey);
@@ -1062,8 +1095,7 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
         WT(const long long c3 = clock64(); wtLeaf += c3 - c2;)
         if (active && next == -1) {
             if (rowLane == 0) {
-                // (hitTri is a slot of the pair stream: the triangle's index in the uploaded stream is looked up here)
-                const int tri = hitTri >= 0 ? sc.slotTri[hitTri] : (bounded ? WF_HIT_UNBLOCKED : hitTri);
+                const int tri = (bounded && hitTri < 0) ? WF_HIT_UNBLOCKED : hitTri;
                 wf.rayHit[slot] = make_int4(tri, __float_as_int(hitT), __float_as_int(hitU), __float_as_int(hitV));
                 if (wantWork) wf.rayWork[slot] = make_int2(iterations, (int)tests);
                 cRays++;
@@ -1174,7 +1206,7 @@ __global__ __launch_bounds__(256) void rt_wf_blend_kernel(RtImages img, WfParams
 
 // ------------------------------------------------------------------------------------------ pair stream
 // One thread per node: a leaf's {v0, e1, e2} records, two triangles per 80-byte record, interleaved component by
-// component (trace3_device.h: testPair), written at the slots its packed node record names; slotTri maps back.
+// component (trace3_device.h: testPair), written at the slots its record in boxesP names; slotTri maps back.
 __global__ __launch_bounds__(256) void rt_build_pairs_kernel(const float4 *__restrict__ boxes, const int2 *__restrict__ leaves,
                                                              int numNodes, const float4 *__restrict__ tris48,
                                                              float4 *__restrict__ pairs, int *__restrict__ slotTri,
@@ -1202,10 +1234,10 @@ __global__ __launch_bounds__(256) void rt_build_pairs_kernel(const float4 *__res
     }
 }
 
-hipError_t rtLaunchBuildPairs(const float4 *boxes, const int2 *leaves, int numNodes, const float4 *tris48, float4 *pairs,
+hipError_t rtLaunchBuildPairs(const float4 *boxesP, const int2 *leaves, int numNodes, const float4 *tris48, float4 *pairs,
                               int *slotTri, int numSlots, hipStream_t stream) {
     if (numNodes <= 0 || numSlots <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rt_build_pairs_kernel, dim3((numNodes + 255) / 256), dim3(256), 0, stream, boxes, leaves, numNodes, tris48,
+    hipLaunchKernelGGL(rt_build_pairs_kernel, dim3((numNodes + 255) / 256), dim3(256), 0, stream, boxesP, leaves, numNodes, tris48,
                        pairs, slotTri, numSlots);
     return hipGetLastError();
 }
@@ -1243,10 +1275,14 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
     const int logicBlocks = 256 * 4;
     // the walk's node fetch is chosen here, once per launch (trace3_device.h: loadNodeT)
     const int extendNodes = !sc.packedLeaves ? NODES_PLAIN : scExtend.cacheNodes >= sc.numNodes ? NODES_PACKED_LDS : NODES_PACKED;
-    auto extendKernel = extendNodes == NODES_PLAIN ? (wt ? rt_wf_extend_kernel<NODES_PLAIN, true> : rt_wf_extend_kernel<NODES_PLAIN, false>)
+    // two triangles per test on packed fp32 (the pair stream): only where its smaller records pay, beyond the L2s
+    const bool pairs = extendNodes != NODES_PLAIN && !wt && sc.boxesP && (p.extendPairs > 0 || (p.extendPairs < 0 && xcdRemap));
+    auto extendKernel = extendNodes == NODES_PLAIN ? (wt ? rt_wf_extend_kernel<NODES_PLAIN, true, false> : rt_wf_extend_kernel<NODES_PLAIN, false, false>)
                         : extendNodes == NODES_PACKED_LDS
-                            ? (wt ? rt_wf_extend_kernel<NODES_PACKED_LDS, true> : rt_wf_extend_kernel<NODES_PACKED_LDS, false>)
-                            : (wt ? rt_wf_extend_kernel<NODES_PACKED, true> : rt_wf_extend_kernel<NODES_PACKED, false>);
+                            ? (wt ? rt_wf_extend_kernel<NODES_PACKED_LDS, true, false>
+                                  : pairs ? rt_wf_extend_kernel<NODES_PACKED_LDS, false, true> : rt_wf_extend_kernel<NODES_PACKED_LDS, false, false>)
+                            : (wt ? rt_wf_extend_kernel<NODES_PACKED, true, false>
+                                  : pairs ? rt_wf_extend_kernel<NODES_PACKED, false, true> : rt_wf_extend_kernel<NODES_PACKED, false, false>);
     // Row mode (one ray per 16-lane row, speculative walk) needs the tree and its decision table in LDS.
     const bool rowsPossible = sc.spec && sc.packedLeaves && sc.numNodes <= RT_SPEC_MAX_NODES && !wt;
     const int rowMode = rowsPossible ? p.rowMode : 0;
