@@ -203,12 +203,14 @@ def roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, root_mis
     bytes_per_launch = alg_bytes / max(launches, 1)
     gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     tops = ops / max(launches, 1) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-    traffic = None
+    traffic = memside = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
-                traffic = json.load(f).get(f"{scene_key}_{W}x{H}_{kname}_bytes_per_launch")
+                tj = json.load(f)
+            traffic = tj.get(f"{scene_key}_{W}x{H}_{kname}_bytes_per_launch")
+            memside = tj.get(f"{scene_key}_{W}x{H}_{kname}_memside")
         except Exception:
             traffic = None
     valu_bound = resident and ops > 0
@@ -217,7 +219,11 @@ def roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, root_mis
          "peak": VALU_PEAK_TOPS_NOFMA if valu_bound else HBM_PEAK_GBS,
          "unit": "TFLOP/s" if valu_bound else "GB/s",
          "frac": round(tops / VALU_PEAK_TOPS_NOFMA if valu_bound else gbs / HBM_PEAK_GBS, 4),
-         "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "launches": launches,
+         "traffic": traffic,
+         "traffic_source": ("profiles/traffic.json: rocprofv3 --pmc passes of this command on the committed build with one frame at a "
+                            "time (scripts/profile.sh, scripts/pmc_memside.sh) - PMC counters cannot be collected inside a timed run; "
+                            "bytes the L2 requested from the fabric (Infinity-Cache hits included), per launch"),
+         "avg_launch_ms": round(avg_ms, 4), "launches": launches,
          "algorithmic_bytes_per_launch": round(bytes_per_launch),
          "algorithmic_ops_per_launch": round(ops / max(launches, 1)),
          "ops_model": "25 fp32 ops per node visit + 51 per triangle test, FMA not used (SURVEY 8(d))",
@@ -228,6 +234,16 @@ def roofline(K, tm, cnt, wl, W, H, spp, filter_iters, steps, scene_key, root_mis
                        "bytes per launch)" if not resident else "streaming kernel: algorithmic bytes against the HBM roof")}
     if not valu_bound and ops > 0:
         r["valu"] = {"achieved_Tops": round(tops, 4), "frac": round(tops / VALU_PEAK_TOPS_NOFMA, 4)}
+    if not valu_bound and not resident:
+        # `achieved` is ALGORITHMIC bytes per second.  Part of them is served by the L2s and, of the L2 misses, part by the
+        # 256 MiB Infinity Cache: what reaches the HBM is less, and no gfx950 counter offered by rocprofv3 separates the two.
+        r["achieved_is"] = ("algorithmic bytes / launch time (L2 hits and Infinity-Cache hits included): an upper bound of the "
+                            "HBM rate, not the HBM rate")
+        if memside:
+            r["memory_side"] = memside
+            if avg_ms > 0 and memside.get("l2_miss_read_bytes_per_launch"):
+                r["memory_side"]["l2_miss_GBs_at_this_launch_time"] = round(
+                    (memside["l2_miss_read_bytes_per_launch"] + memside.get("write_bytes_per_launch", 0)) / (avg_ms * 1e-3) / 1e9, 1)
     if valu_bound:
         r["algorithmic_GBs"] = round(gbs, 2)
     return r

@@ -53,11 +53,11 @@ constexpr size_t kStaticState16 = alignUp((size_t)RT_STATIC_MAX_PATHS * 16);    
 constexpr size_t kStaticState8 = alignUp((size_t)RT_STATIC_MAX_PATHS * 8);        // pixSample
 constexpr size_t kStaticRay16 = alignUp((size_t)3 * RT_STATIC_MAX_PATHS * 16);    // rayO[2], rayD[2], rayHit
 constexpr size_t kStaticRay8 = alignUp((size_t)3 * RT_STATIC_MAX_PATHS * 8);      // rayWork
-constexpr size_t kStaticQueue = alignUp((size_t)RT_STATIC_MAX_PATHS * 4);         // queue[2]
+constexpr size_t kStaticQueue = alignUp((size_t)RT_STATIC_MAX_PATHS * 4);         // primPix
 constexpr size_t kStaticCounts = alignUp(64 * sizeof(int));
 constexpr size_t kStaticRadiance = alignUp((size_t)RT_STATIC_MAX_PATHS * 16);
-constexpr size_t kStaticBytes = 7 * kStaticState16 + kStaticState8 + 5 * kStaticRay16 + kStaticRay8 + 3 * kStaticQueue +
-                                kStaticCounts + kStaticRadiance; // (3 queues: two path queues + the stage-0 pixel queue)
+constexpr size_t kStaticBytes = 2 * (7 * kStaticState16 + kStaticState8) + 5 * kStaticRay16 + kStaticRay8 + kStaticQueue +
+                                kStaticCounts + kStaticRadiance; // (two sets of path state; one queue: the stage-0 pixel queue)
 } // namespace
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 #define RT_MAX_DEVICES 64
@@ -670,14 +670,14 @@ int ensureWavefront(rt_ctx *c, rt_ctx::Lane &L, size_t capacity, size_t radiance
     if (capacity > L.wfCapacity) {
         // grow with some slack so that tiles of slightly different sizes do not re-allocate
         const size_t cap = capacity + capacity / 16;
+        // (state sets 0 and 1 of a record lie behind each other in one allocation)
         for (int k = 0; k < 6; ++k)
-            if ((r = ensure(c, L.wfState[k], cap * 16))) return r;
-        if ((r = ensure(c, L.wfState[6], cap * 8))) return r;  // pixSample
-        if ((r = ensure(c, L.wfState[7], cap * 16))) return r; // pathStats
+            if ((r = ensure(c, L.wfState[k], 2 * cap * 16))) return r;
+        if ((r = ensure(c, L.wfState[6], 2 * cap * 8))) return r;  // pixSample
+        if ((r = ensure(c, L.wfState[7], 2 * cap * 16))) return r; // pathStats
         for (int k = 0; k < 5; ++k)
             if ((r = ensure(c, L.wfRay[k], 3 * cap * 16))) return r;
         if ((r = ensure(c, L.wfRay[5], 3 * cap * 8))) return r;
-        if ((r = ensure(c, L.wfQueue[0], cap * 4)) || (r = ensure(c, L.wfQueue[1], cap * 4))) return r;
         if ((r = ensure(c, L.wfPrimPix, cap * 4))) return r;
         L.wfCapacity = cap;
     }
@@ -686,22 +686,23 @@ int ensureWavefront(rt_ctx *c, rt_ctx::Lane &L, size_t capacity, size_t radiance
         if ((r = ensure(c, L.wfRadiance, radianceSlots * 16))) return r;
         L.wfRadianceSlots = radianceSlots;
     }
-    wf.L_seed = (float4 *)L.wfState[0].p;
-    wf.beta = (float4 *)L.wfState[1].p;
-    wf.betaOld = (float4 *)L.wfState[2].p;
-    wf.f1w1 = (float4 *)L.wfState[3].p;
-    wf.f2w2 = (float4 *)L.wfState[4].p;
-    wf.pdfs = (float4 *)L.wfState[5].p;
-    wf.pixSample = (uint2 *)L.wfState[6].p;
-    wf.pathStats = (int4 *)L.wfState[7].p;
+    const size_t cap = L.wfCapacity;
+    for (int k = 0; k < 2; ++k) {
+        wf.L_seed[k] = (float4 *)L.wfState[0].p + k * cap;
+        wf.beta[k] = (float4 *)L.wfState[1].p + k * cap;
+        wf.betaOld[k] = (float4 *)L.wfState[2].p + k * cap;
+        wf.f1w1[k] = (float4 *)L.wfState[3].p + k * cap;
+        wf.f2w2[k] = (float4 *)L.wfState[4].p + k * cap;
+        wf.pdfs[k] = (float4 *)L.wfState[5].p + k * cap;
+        wf.pixSample[k] = (uint2 *)L.wfState[6].p + k * cap;
+        wf.pathStats[k] = (int4 *)L.wfState[7].p + k * cap;
+    }
     wf.rayO[0] = (float4 *)L.wfRay[0].p;
     wf.rayO[1] = (float4 *)L.wfRay[1].p;
     wf.rayD[0] = (float4 *)L.wfRay[2].p;
     wf.rayD[1] = (float4 *)L.wfRay[3].p;
     wf.rayHit = (int4 *)L.wfRay[4].p;
     wf.rayWork = (int2 *)L.wfRay[5].p;
-    wf.queue[0] = (int *)L.wfQueue[0].p;
-    wf.queue[1] = (int *)L.wfQueue[1].p;
     wf.counts = (int *)L.wfCounts.p;
     wf.radiance = (float4 *)L.wfRadiance.p;
     wf.primPix = (unsigned *)L.wfPrimPix.p;
@@ -798,7 +799,9 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         c->lastWalkSettled = settled;
     }
     // (the frames that time the schedule candidates must not differ in anything else)
-    wp.extendBlocksDense = settled ? c->tuneExtendBlocksDense : c->tuneExtendBlocks;
+    // (three blocks per CU pay when several frames share the GPU — room.obj 33.3 -> 32.2 ms with four in flight —; a frame
+    // that has it to itself wants the four: 4.75 against 5.53 ms per dense extend launch)
+    wp.extendBlocksDense = (settled && beforeCommit) ? c->tuneExtendBlocksDense : c->tuneExtendBlocks;
     wp.extendChunk = c->tuneChunk;
     // full waves test their leaves cooperatively when the triangles do not fit the L2s (measured on MI355X: the
     // coalesced triangle reads of that scheme win on the 1.7 M-triangle lattice, 3.66 -> 3.28 ms, and lose to
@@ -1119,14 +1122,16 @@ int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const
     size_t off = 0;
     auto take = [&](size_t bytes) { unsigned char *q = base + off; off += bytes; return q; };
     WfBuffers wf;
-    wf.L_seed = (float4 *)take(kStaticState16);
-    wf.beta = (float4 *)take(kStaticState16);
-    wf.betaOld = (float4 *)take(kStaticState16);
-    wf.f1w1 = (float4 *)take(kStaticState16);
-    wf.f2w2 = (float4 *)take(kStaticState16);
-    wf.pdfs = (float4 *)take(kStaticState16);
-    wf.pathStats = (int4 *)take(kStaticState16);
-    wf.pixSample = (uint2 *)take(kStaticState8);
+    for (int k = 0; k < 2; ++k) {
+        wf.L_seed[k] = (float4 *)take(kStaticState16);
+        wf.beta[k] = (float4 *)take(kStaticState16);
+        wf.betaOld[k] = (float4 *)take(kStaticState16);
+        wf.f1w1[k] = (float4 *)take(kStaticState16);
+        wf.f2w2[k] = (float4 *)take(kStaticState16);
+        wf.pdfs[k] = (float4 *)take(kStaticState16);
+        wf.pathStats[k] = (int4 *)take(kStaticState16);
+        wf.pixSample[k] = (uint2 *)take(kStaticState8);
+    }
     wf.rayO[0] = (float4 *)take(kStaticRay16);
     wf.rayO[1] = (float4 *)take(kStaticRay16);
     wf.rayD[0] = (float4 *)take(kStaticRay16);
@@ -1137,8 +1142,6 @@ int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const
     wf.stagePos = nullptr;
     wf.flat = RtFlatCells{};
     c->flatValid = false;
-    wf.queue[0] = (int *)take(kStaticQueue);
-    wf.queue[1] = (int *)take(kStaticQueue);
     wf.primPix = (unsigned *)take(kStaticQueue);
     wf.counts = (int *)take(kStaticCounts);
     wf.radiance = (float4 *)take(kStaticRadiance);

@@ -36,15 +36,19 @@ struct WfParams {
 };
 
 struct WfBuffers {
-    // path state, indexed by path id (= slot given at the primary hit)
-    float4 *L_seed;     // L.xyz, bits(seed)
-    float4 *beta;       // beta.xyz after the bounce's update, bits(pathFlags)
-    float4 *betaOld;    // beta.xyz the bounce's direct light is weighted with, bits(light index)
-    float4 *f1w1;       // light-sample term f1.xyz, MIS weight
-    float4 *f2w2;       // BRDF-sample term f2.xyz, MIS weight
-    float4 *pdfs;       // lp1, bp2, bits(cond1 | cond2<<1), unused
-    uint2 *pixSample;   // pixel index, sample index
-    int4 *pathStats;    // rays, visits, tests (RT_FLAG_PIXEL_STATS)
+    // Path state, indexed by the path's position in its stage's queue and double-buffered by stage parity: logic(b)
+    // reads set b & 1 at its own queue position i and writes set (b + 1) & 1 at the position the path gets in the next
+    // stage's queue, so every access is a dense, coalesced 16-byte record per lane.  (Round 2 indexed the state by a
+    // path id fixed at the primary hit and kept queues of ids: as paths ended, the survivors' records lay scattered
+    // and a 16-byte read pulled in a whole line — 2.8 GB of HBM traffic per room.obj launch for 0.8 GB of state.)
+    float4 *L_seed[2];  // L.xyz, bits(seed)
+    float4 *beta[2];    // beta.xyz after the bounce's update, bits(pathFlags)
+    float4 *betaOld[2]; // beta.xyz the bounce's direct light is weighted with, bits(light index)
+    float4 *f1w1[2];    // light-sample term f1.xyz, MIS weight
+    float4 *f2w2[2];    // BRDF-sample term f2.xyz, MIS weight
+    float4 *pdfs[2];    // lp1, bp2, bits(cond1 | cond2<<1), light_prob
+    uint2 *pixSample[2]; // pixel index, sample index
+    int4 *pathStats[2]; // rays, visits, tests (RT_FLAG_PIXEL_STATS)
     // ray queue: slot = kind * capacity + queue position
     // origins / directions are double-buffered by stage parity: logic(b) reads the rays of stage b
     // (the continuation ray that produced its hit) while it writes the rays of stage b+1
@@ -52,7 +56,6 @@ struct WfBuffers {
     float4 *rayD[2];    // dir.xyz
     int4 *rayHit;       // tridx, bits(t), bits(u), bits(v)
     int2 *rayWork;      // visits, tests of that traversal
-    int *queue[2];      // path ids, ping-pong
     int *counts;        // [0..31] queue sizes per stage, [32..63] work cursors per stage
     unsigned *primPix;  // stage-0 queue: pixel index of entry j (one entry per PIXEL: the primary ray is the same for
                         // every sample of a batch, trace3.cs:805-806, so it is traced once and logic(0) fans out)

@@ -199,8 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     // bounce 0: the stage-0 queue holds one entry per pixel (the shared primary hit); every sample of the batch becomes
     // a path of its own here: lane i = (entry i / batch, sample i % batch), path id = i
     const int n = bounce == 0 ? min(wf.counts[0] * p.batch, wf.capacity) : min(wf.counts[bounce], wf.capacity);
-    const int *qin = wf.queue[bounce & 1];
-    int *qout = wf.queue[(bounce + 1) & 1];
+    const int rb = bounce & 1, wb = rb ^ 1; // path-state sets read / written by this stage (wavefront.h)
     const size_t cap = (size_t)wf.capacity;
     const int W = img.width;
     const int rounds = (n + (int)(gridDim.x * blockDim.x) - 1) / (int)(gridDim.x * blockDim.x);
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         // across the queue append below is only what part 2 needs (the kernel is register-bound: every value held
         // here costs occupancy).
         bool requeue = false;
-        int pid = 0, pix = 0, sample = 0, seed = 0;
+        int pix = 0, sample = 0, seed = 0;
         f3 L = F3(0, 0, 0), beta = F3(0, 0, 0), dir = F3(0, 0, 0);
         Surface SI;
         SI.tridx = -1; SI.matidx = 0; SI.normal = SI.point = F3(0, 0, 0);
@@ -224,27 +223,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             if (bounce == 0) {
                 const int entry = i / p.batch;
                 sample = i - entry * p.batch;
-                pid = i;
                 pix = (int)wf.primPix[entry];
                 beta = F3(1.0f, 1.0f, 1.0f);
                 hitRay = 2 * cap + entry;
             } else {
-                pid = qin[i];
-                const uint2 ps = wf.pixSample[pid];
+                const uint2 ps = wf.pixSample[rb][i];
                 pix = (int)ps.x;
                 sample = (int)ps.y;
-                const float4 Ls = wf.L_seed[pid];
-                const float4 bt = wf.beta[pid];
+                const float4 Ls = wf.L_seed[rb][i];
+                const float4 bt = wf.beta[rb][i];
                 L = F3(Ls.x, Ls.y, Ls.z);
                 beta = F3(bt.x, bt.y, bt.z);
                 seed = __float_as_int(Ls.w);
                 flags = __float_as_int(bt.w);
-                if (wantStats) stats = wf.pathStats[pid];
+                if (wantStats) stats = wf.pathStats[rb][i];
             }
 
             if (flags & WF_FLAG_PENDING) {
                 // finish EstimateDirect of the previous bounce (trace3.cs:533-571) and L += beta * Ld (:652)
-                const float4 bo = wf.betaOld[pid], a1 = wf.f1w1[pid], a2 = wf.f2w2[pid], pd = wf.pdfs[pid];
+                const float4 bo = wf.betaOld[rb][i], a1 = wf.f1w1[rb][i], a2 = wf.f2w2[rb][i], pd = wf.pdfs[rb][i];
                 const int li = __float_as_int(bo.w);
                 const LightTri light = loadLight(sc, li);
                 const int conds = __float_as_int(pd.z);
@@ -327,9 +324,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             {
                 DirectTerms T;
                 estimateDirectPrepare(c, o2, dir, SI.normal, m, bounce, light, T);
-                wf.f1w1[pid] = make_float4(T.f1.x, T.f1.y, T.f1.z, T.w1);
-                wf.f2w2[pid] = make_float4(T.f2.x, T.f2.y, T.f2.z, T.w2);
-                wf.pdfs[pid] = make_float4(T.lp1, T.bp2, __int_as_float(T.cond1 | (T.cond2 << 1)), light_prob);
+                wf.f1w1[wb][slot] = make_float4(T.f1.x, T.f1.y, T.f1.z, T.w1);
+                wf.f2w2[wb][slot] = make_float4(T.f2.x, T.f2.y, T.f2.z, T.w2);
+                wf.pdfs[wb][slot] = make_float4(T.lp1, T.bp2, __int_as_float(T.cond1 | (T.cond2 << 1)), light_prob);
                 float t1 = 0.0f, t2 = 0.0f, c1 = 1.0f, c2 = 1.0f;
                 if (p.flags & RT_FLAG_FAST_SHADOWS) { // rd.w = distance of the light; rays that miss it are not cast
                     t1 = lightDistance(light, o2, T.wi1);
@@ -344,16 +341,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 outO[cap + slot] = make_float4(o2.x, o2.y, o2.z, c2);
                 outD[cap + slot] = make_float4(T.wi2.x, T.wi2.y, T.wi2.z, t2);
             }
-            wf.betaOld[pid] = make_float4(beta.x, beta.y, beta.z, __int_as_float(li));
+            wf.betaOld[wb][slot] = make_float4(beta.x, beta.y, beta.z, __int_as_float(li));
             f3 wi;
             const bool alive = continuePath(c, bounce, SI.normal, m, dir, beta, wi);
             outO[2 * cap + slot] = make_float4(o2.x, o2.y, o2.z, alive ? 1.0f : 0.0f);
             outD[2 * cap + slot] = make_float4(wi.x, wi.y, wi.z, 0.0f);
-            if (bounce == 0) wf.pixSample[pid] = make_uint2((unsigned)pix, (unsigned)sample);
-            wf.L_seed[pid] = make_float4(L.x, L.y, L.z, __int_as_float(c.seed));
-            wf.beta[pid] = make_float4(beta.x, beta.y, beta.z, __int_as_float(WF_FLAG_PENDING | (alive ? 0 : WF_FLAG_ENDED)));
-            if (wantStats) wf.pathStats[pid] = stats;
-            qout[slot] = pid;
+            wf.pixSample[wb][slot] = make_uint2((unsigned)pix, (unsigned)sample);
+            wf.L_seed[wb][slot] = make_float4(L.x, L.y, L.z, __int_as_float(c.seed));
+            wf.beta[wb][slot] = make_float4(beta.x, beta.y, beta.z, __int_as_float(WF_FLAG_PENDING | (alive ? 0 : WF_FLAG_ENDED)));
+            if (wantStats) wf.pathStats[wb][slot] = stats;
         }
     }
     if (!(p.flags & RT_FLAG_NO_COUNTERS)) waveAdd(&counterShard(counters)->shaded_hits, shaded);
@@ -1243,7 +1239,7 @@ hipError_t rtLaunchBuildPairs(const float4 *boxesP, const int2 *leaves, int numN
 }
 
 // ------------------------------------------------------------------------------------------ host
-size_t rtWavefrontBytesPerPath() { return 6 * 16 + 8 + 16 + 3 * (4 * 16 + 16 + 8) + 2 * 4; }
+size_t rtWavefrontBytesPerPath() { return 2 * (6 * 16 + 8 + 16) + 3 * (4 * 16 + 16 + 8) + 4; }
 
 hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const WfParams &p, const WfBuffers &wf,
                              const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream,
