@@ -85,6 +85,12 @@ int rth_tile_rect(int width, int height, int world, int rank, int halo, int32_t 
  * filterOn} (in/out).  Returns 0. */
 int rth_input_event(int key, double scroll, float state[11], int32_t ints[4]);
 
+/* Mouse-look (reference src/glfw_setter.cpp:239-302): n cursor positions xy = {x0, y0, x1, y1, ...} fed in order to a
+ * fresh handler on the camera state = {eye[3], lookAt[3], up[3]} (lookAt in/out).  The first position only sets the
+ * reference point; every later one turns the camera by 0.05 degrees per pixel and restarts the accumulation.  Returns the
+ * frame number the handler leaves (frameNumber if the camera never turned, else 0), or -1 on a bad argument. */
+int rth_mouse_events(const double *xy, int n, float state[9], int32_t frameNumber);
+
 /* FrameBuffer::saveToImage (reference src/FrameBuffer.cpp:89-107): 8-bit RGBA PNG, rows
  * flipped vertically when flip != 0. */
 int rth_write_png(const char *path, int width, int height, const uint8_t *rgba, int flip);

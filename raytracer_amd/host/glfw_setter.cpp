@@ -21,6 +21,11 @@ int *GlfwSetter::maxBounces = nullptr;
 bool GlfwSetter::filter = false;
 float GlfwSetter::exposure = 1.0f;
 bool GlfwSetter::extendedKeys = false;
+int GlfwSetter::lastX = 0;
+int GlfwSetter::lastY = 0;
+float GlfwSetter::yaw = 0;
+float GlfwSetter::pitch = 0;
+bool GlfwSetter::firstMouse = true;
 
 void GlfwSetter::reset() {
     framebuffer = nullptr;
@@ -32,6 +37,9 @@ void GlfwSetter::reset() {
     maxAccumulateSamples = iterations = maxBounces = nullptr;
     filter = false;
     exposure = 1.0f;
+    lastX = lastY = 0;
+    yaw = pitch = 0;
+    firstMouse = true;
 }
 
 namespace {
@@ -102,4 +110,42 @@ void GlfwSetter::scroll_callback(double, double yoffset) {
     const float tempfov = camera->fov;
     camera->fov = (float)std::max(std::min((double)camera->fov - yoffset, 100.0), 45.0);
     if (camera->fov != tempfov) frameNumber = 0;
+}
+
+namespace {
+
+const double kDegPerRad = 57.295779513082320876798154814105; // glm::degrees / glm::radians in double
+double toDegrees(double r) { return r * kDegPerRad; }
+double toRadians(double d) { return d * 0.01745329251994329576923690768489; }
+
+} // namespace
+
+void GlfwSetter::mouse_callback(double xpos, double ypos) {
+    if (!camera) return;
+    if (firstMouse) {
+        // the angles of the current viewing direction: pitch from y; yaw from asin(z) and acos(x) of the horizontal part,
+        // pieced together per quadrant into (-90, 270] degrees (glfw_setter.cpp:246-280)
+        lastX = (int)xpos;
+        lastY = (int)ypos;
+        const vec3 d = normalized(camera->lookAt - camera->eye);
+        const double p = toDegrees(std::asin(d.y));
+        pitch = (float)p;
+        const double horizontal = std::cos(toRadians(p));
+        const double fromZ = toDegrees(std::asin(d.z / horizontal)), fromX = toDegrees(std::acos(d.x / horizontal));
+        const bool front = fromX < 90.0; // x > 0
+        yaw = (float)(fromZ > 0 ? (front ? fromZ : fromX) : (front ? fromZ : 180.0 - fromZ));
+        firstMouse = false;
+        return;
+    }
+    const float sensitivity = 0.05f;
+    const float dx = (float)(xpos - lastX) * sensitivity, dy = (float)(lastY - ypos) * sensitivity;
+    lastX = (int)xpos;
+    lastY = (int)ypos;
+    const float turned = yaw + dx;
+    yaw = turned - 360.0f * std::floor(turned / 360.0f); // glm::mod
+    pitch = std::min(89.0f, std::max(-89.0f, pitch + dy));
+    const float yr = yaw * 0.01745329251994329576923690768489f, pr = pitch * 0.01745329251994329576923690768489f;
+    const vec3 direction(std::cos(yr) * std::cos(pr), std::sin(pr), std::sin(yr) * std::cos(pr));
+    camera->lookAt = camera->eye + normalized(direction);
+    frameNumber = 0;
 }

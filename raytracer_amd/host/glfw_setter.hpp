@@ -2,8 +2,9 @@
 // (reference include/glfw_setter.hpp:37-49, src/glfw_setter.cpp:77-237,304-310): which inputs move the camera, which
 // reset the progressive accumulation (frameNumber = 0), which toggle the filter / change bounces, iterations, exposure.
 // A headless run feeds it scripted events (rt_headless --keys "FRAME:KEY,..."), so that "camera change -> accumulation
-// restarts" can be exercised and tested without GLFW.  Window creation, cursor capture, the mouse-look arithmetic and
-// the F10 / ESC bindings stay out of scope (component 18).
+// restarts" can be exercised and tested without GLFW.  Mouse-look (src/glfw_setter.cpp:239-302) is here too: a cursor
+// position turns the camera and restarts the accumulation.  Window creation, cursor capture and the F10 / ESC bindings
+// stay out of scope (component 18).
 #ifndef RT_AMD_GLFW_SETTER_HPP
 #define RT_AMD_GLFW_SETTER_HPP
 
@@ -33,6 +34,12 @@ public:
     // (C, B, F, T, UP, DOWN: :177-206) are live here only when `extendedKeys` is set.
     static void key_callback(int key, int scancode, int action, int mods);
     static void scroll_callback(double xoffset, double yoffset); // :304-310
+    // :239-302.  The first position only sets the reference point and reads yaw / pitch off the camera; later ones
+    // turn the camera by 0.05 degrees per pixel (pitch clamped to +-89) and restart the accumulation.
+    static void mouse_callback(double xpos, double ypos);
+    static int lastX, lastY; // (whole pixels, as in the reference: reference include/glfw_setter.hpp:25)
+    static float yaw, pitch;
+    static bool firstMouse;
     static bool extendedKeys;
     static void reset(); // back to the initial values of glfw_setter.cpp:3-23
 };

@@ -77,6 +77,23 @@ int rth_input_event(int key, double scroll, float state[11], int32_t ints[4]) {
     return 0;
 }
 
+// GlfwSetter::mouse_callback on a camera given as state[0..8] = eye, lookAt, up: n cursor positions (x0, y0, x1, y1, ...)
+// fed in order to a fresh handler (the first only sets the reference point).  Returns the frame number it leaves
+// (0 once the camera has turned) and the new lookAt in state[3..5].
+int rth_mouse_events(const double *xy, int n, float state[9], int32_t frameNumber) {
+    if (!xy || !state || n < 0) return -1;
+    Camera cam(vec3(state[0], state[1], state[2]), vec3(state[3], state[4], state[5]), vec3(state[6], state[7], state[8]),
+               60.0f, 1.0f, 1.0f, 1.0f, 2.0f);
+    GlfwSetter::reset();
+    GlfwSetter::camera = &cam;
+    GlfwSetter::frameNumber = frameNumber;
+    for (int i = 0; i < n; ++i) GlfwSetter::mouse_callback(xy[2 * i], xy[2 * i + 1]);
+    state[3] = cam.lookAt.x; state[4] = cam.lookAt.y; state[5] = cam.lookAt.z;
+    const int fn = GlfwSetter::frameNumber;
+    GlfwSetter::reset();
+    return fn;
+}
+
 rth_scene *rth_scene_load_obj(const char *path) {
     if (!path) return nullptr;
     FILE *f = std::fopen(path, "rb");

@@ -7,7 +7,8 @@
 // as the reference's main does, but not traced); trace1 / trace2 read their tables from --res (default "res").
 // --keys feeds the reference's input handler (glfw_setter.hpp) before the given frame of the loop: W A S D Z X move the
 // camera and restart the accumulation, COMMA / PERIOD change maxBounces (restart), SPACE toggles the filter, MINUS /
-// EQUAL change its iterations, 1 / 2 the exposure, SCROLL+n / SCROLL-n the field of view; --reset-at K stands for any
+// EQUAL change its iterations, 1 / 2 the exposure, SCROLL+n / SCROLL-n the field of view, MOUSE<x>x<y> moves the cursor
+// (mouse-look: the first position is the reference point, later ones turn the camera); --reset-at K stands for any
 // input that only resets frameNumber at frame K.  --gpus N renders on N GPUs of this node, one host thread and one
 // launcher context per GPU: the frame is split into screen-space tiles (tiling.hpp), every GPU traces its tile plus the
 // filter halo and filters it locally, rt_gather_tiles assembles the frame on GPU 0 over RCCL.
@@ -77,6 +78,13 @@ bool scriptStates(const Options &o, Camera camera, std::vector<FrameState> &stat
             if (k.first != f) continue;
             if (k.second.rfind("SCROLL", 0) == 0) {
                 GlfwSetter::scroll_callback(0.0, std::atof(k.second.c_str() + 6));
+            } else if (k.second.rfind("MOUSE", 0) == 0) { // MOUSE<x>x<y>: a cursor position (the first one only sets the reference point)
+                double mx = 0, my = 0;
+                if (std::sscanf(k.second.c_str() + 5, "%lfx%lf", &mx, &my) != 2) {
+                    std::cerr << "bad mouse event " << k.second << " (MOUSE<x>x<y>)" << std::endl;
+                    return false;
+                }
+                GlfwSetter::mouse_callback(mx, my);
             } else {
                 const int code = keyCode(k.second);
                 if (code < 0) {

@@ -63,6 +63,8 @@ def lib():
         L.rth_tile_rect.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int32 * 4), ctypes.POINTER(ctypes.c_int32 * 2)]
         L.rth_input_event.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_float * 11),
                                       ctypes.POINTER(ctypes.c_int32 * 4)]
+        L.rth_mouse_events.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.c_int, ctypes.POINTER(ctypes.c_float * 9),
+                                       ctypes.c_int32]
         _lib = L
     return _lib
 
@@ -213,6 +215,17 @@ def tile_rect(width, height, world, rank, halo):
 
 
 KEYS = dict(W=87, A=65, S=83, D=68, Z=90, X=88, COMMA=44, PERIOD=46, SPACE=32, MINUS=45, EQUAL=61, K1=49, K2=50)
+
+
+def mouse_events(camera, positions, frame_number=7):
+    """Mouse-look (glfw_setter.cpp:239-302): cursor positions [(x, y), ...] through a fresh handler.
+    Returns (look_at, frame_number)."""
+    st = (ctypes.c_float * 9)(*camera["eye"], *camera["look_at"], *camera["up"])
+    xy = (ctypes.c_double * (2 * len(positions)))(*[float(v) for p in positions for v in p])
+    fn = lib().rth_mouse_events(xy, len(positions), ctypes.byref(st), int(frame_number))
+    if fn < 0:
+        raise RuntimeError("rth_mouse_events")
+    return tuple(st[3:6]), fn
 
 
 def input_event(camera, frame_number, max_bounces, iterations, filter_on, exposure=1.0, key=0, scroll=0.0):

@@ -155,3 +155,45 @@ def test_input_state_machine_follows_glfw_setter():
     assert cam["fov"] == 55.0 and fn == 0
     cam, fn, *_ = hostlib.input_event(dict(cam0, fov=45.0), 8, 5, 2, False, scroll=3.0)
     assert cam["fov"] == 45.0 and fn == 8
+
+
+def test_mouse_look_state_machine():
+    """Mouse-look (reference src/glfw_setter.cpp:239-302): the first cursor position only sets the reference point and
+    reads yaw / pitch off the camera — whatever the quadrant it looks into —, later ones turn it by 0.05 degrees per pixel
+    (x: yaw, y: pitch, up = smaller y), pitch stays within +-89 degrees, every turn restarts the accumulation."""
+    import math
+    eye = (0.5, 2.0, -1.0)
+    up = (0.0, 1.0, 0.0)
+
+    def cam(d):
+        n = math.sqrt(sum(v * v for v in d))
+        return dict(eye=eye, look_at=tuple(e + v / n * 3.0 for e, v in zip(eye, d)), up=up)   # (any distance along d)
+
+    def direction(look_at):
+        d = np.array(look_at, np.float64) - np.array(eye, np.float64)
+        return d / np.linalg.norm(d)
+
+    # the first event alone changes nothing and does not restart the accumulation
+    look, fn = hostlib.mouse_events(cam((0.3, 0.2, -1.0)), [(100, 100)], frame_number=7)
+    assert fn == 7 and np.allclose(look, cam((0.3, 0.2, -1.0))["look_at"], atol=1e-6)
+    # a second event at the SAME position: no turn, but lookAt is rebuilt from the angles at distance 1 — the same
+    # direction in all four quadrants (and for the reference's camera), and frameNumber = 0
+    for d in [(1.0, 0.3, 2.0), (-1.0, 0.3, 2.0), (-1.0, -0.2, -2.0), (1.0, 0.1, -2.0), (0.0, 0.8, -3.5)]:
+        look, fn = hostlib.mouse_events(cam(d), [(10, 20), (10, 20)])
+        want = np.array(d) / np.linalg.norm(d)
+        # (looking straight down -z, yaw comes from asin of a value within rounding of -1: the reference's formula is
+        # ill-conditioned there and so is its restatement — a few 1e-4, which the handler then keeps)
+        tol = 1e-3 if d[0] == 0.0 else 2e-6
+        assert fn == 0 and np.allclose(direction(look), want, atol=tol), (d, direction(look), want)
+        assert abs(np.linalg.norm(np.array(look) - np.array(eye)) - 1.0) < 1e-6
+    # 40 pixels to the right = +2 degrees of yaw (about +y, from +x towards +z); 30 pixels up = +1.5 degrees of pitch
+    d0 = np.array((1.0, 0.0, 0.0))
+    look, fn = hostlib.mouse_events(cam(tuple(d0)), [(0, 0), (40, 0)])
+    assert np.allclose(direction(look), (math.cos(math.radians(2)), 0.0, math.sin(math.radians(2))), atol=2e-6)
+    look, fn = hostlib.mouse_events(cam(tuple(d0)), [(0, 100), (0, 70)])
+    assert np.allclose(direction(look), (math.cos(math.radians(1.5)), math.sin(math.radians(1.5)), 0.0), atol=2e-6)
+    # events accumulate; pitch is clamped to 89 degrees
+    look, fn = hostlib.mouse_events(cam(tuple(d0)), [(0, 0), (0, -1000), (0, -3000)])
+    assert abs(math.degrees(math.asin(direction(look)[1])) - 89.0) < 1e-3
+    look, fn = hostlib.mouse_events(cam(tuple(d0)), [(0, 0), (7200, 0)])          # a full turn: yaw is taken modulo 360
+    assert np.allclose(direction(look), d0, atol=1e-5)
