@@ -103,7 +103,15 @@ enum rt_flags {
      * undefined: no emitter faces the point -> the uniform pick; rounding leaves the cumulative sum below the
      * random number -> the last emitter of non-zero weight.  Same random numbers consumed as without the flag.
      * RT_KERNEL_TRACE3 only. */
-    RT_FLAG_WEIGHTED_LIGHTS = 64
+    RT_FLAG_WEIGHTED_LIGHTS = 64,
+    /* NOT a mode of the reference's trace3.cs; off by default; "parity unpinned by construction" (the reference has the
+     * blue-noise Sobol sampler only in its box-scene kernel, reference src/shaders/trace1.cs:201-229 — RT_KERNEL_TRACE1 here,
+     * pinned by llvmpipe fixtures).  With this flag trace() draws its random numbers from that sampler: the k-th number
+     * of bounce s (k = 0..9: light pick, specular / diffuse choice, light sample x 2, BRDF sample x 2, continuation x 3,
+     * roulette) is sampleBlueNoise(10 * s + k) with sampleIndex = params.frameIndex, instead of the hash of
+     * trace3.cs:280-301.  Needs the sobol, scramble and ranking tables (rt_set_table; RT_ESTATE without them).
+     * RT_KERNEL_TRACE3 only (both schedules, and rt_trace_batch_static).  Checked against the CPU oracle's same mode. */
+    RT_FLAG_BLUE_NOISE = 128
 };
 
 typedef struct rt_rect {

@@ -24,7 +24,9 @@ class OrcTraceParams(ctypes.Structure):
                 ("max_bounces", ctypes.c_int32), ("num_emitters", ctypes.c_int32),
                 ("max_follows", ctypes.c_int32), ("oob_seeds", ctypes.c_float * 3),
                 ("x0", ctypes.c_int32), ("y0", ctypes.c_int32), ("x1", ctypes.c_int32), ("y1", ctypes.c_int32),
-                ("weighted_lights", ctypes.c_int32)]
+                ("weighted_lights", ctypes.c_int32),
+                ("blue_noise", ctypes.c_int32), ("frame_index", ctypes.c_int32),
+                ("sobol", ctypes.c_void_p), ("scramble", ctypes.c_void_p), ("ranking", ctypes.c_void_p)]
 
 
 class OrcAnalyticParams(ctypes.Structure):
@@ -112,8 +114,11 @@ def weighted_fallbacks(reset=True):
 
 
 def trace(scene, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.0625, max_bounces=5,
-          num_emitters=None, color=None, rect=None, max_follows=1000, oob='llvmpipe', weighted_lights=False, light_pick_probe=False):
-    """spp dispatches with time_k = time0 + dtime*k, blendFactor_k = k/(k+1) (as tests/golden fixtures)."""
+          num_emitters=None, color=None, rect=None, max_follows=1000, oob='llvmpipe', weighted_lights=False, light_pick_probe=False,
+          blue_noise=None):
+    """spp dispatches with time_k = time0 + dtime*k, blendFactor_k = k/(k+1) (as tests/golden fixtures).
+    blue_noise: {"sobol", "scramble", "ranking": bytes} -> orc_trace_params::blue_noise with frame_index = the sample's index
+    (not a mode of the reference: see rt_oracle.h)."""
     L = lib()
     n = width * height
     color = np.zeros((height, width, 4), np.float32) if color is None else np.ascontiguousarray(color, np.float32).copy()
@@ -133,9 +138,17 @@ def trace(scene, width, height, rays, eye, spp=1, frame0=0, time0=1.25, dtime=0.
     p.weighted_lights = int(bool(weighted_lights)) | (2 if light_pick_probe else 0)
     if rect is not None:
         p.x0, p.y0, p.x1, p.y1 = rect
+    keep = []
+    if blue_noise is not None:
+        p.blue_noise = 1
+        for name in ("sobol", "scramble", "ranking"):
+            a = np.frombuffer(bytes(blue_noise[name]), np.uint8).copy()
+            keep.append(a)
+            setattr(p, name, a.ctypes.data)
     stats_sum = np.zeros((height, width, 4), np.int64)
     for k in range(spp):
         frame = frame0 + k
+        p.frame_index = frame
         p.time = float(np.float32(time0) + np.float32(dtime) * np.float32(frame))
         p.blend_factor = float(np.float32(frame) / (np.float32(frame) + np.float32(1.0)))
         if oob == 'llvmpipe':

@@ -275,6 +275,9 @@ typedef struct {
     int num_emitters_uniform;
     int weighted_lights; /* randomEmitterSample's commented-out block (random.glsl:223-248) instead of the uniform pick */
     float oob_seeds[3];
+    /* orc_trace_params::blue_noise: the tables, the sample index and the numbers drawn so far at this bounce */
+    int blue, frame_index, drawn;
+    const uint8_t *sobol, *scramble, *ranking;
     /* instrumentation */
     int last_iterations;
     int rays, visits, tests;
@@ -303,7 +306,24 @@ static inline float seedAt(const float *oob, int i) {
     if (i >= 0 && i < 13) return rand_seeds[i];
     return (i >= -3 && i < 0) ? oob[-1 - i] : 0.0f;
 }
-static inline float rnd(const ctx_t *c, int s, int idx) {
+/* sampleBlueNoise, trace1.cs:201-213, on explicit tables (reads past a table's end give 0, as on the oracle platform) */
+static inline uint32_t blueTableAt(const uint8_t *t, uint32_t n, uint32_t i) { return (t && i < n) ? t[i] : 0u; }
+static float blueSample(const uint8_t *sobol, const uint8_t *scramble, const uint8_t *ranking, int px, int py, int frame_index,
+                        uint32_t dim) {
+    uint32_t xoff = orc_hash3((uint32_t)(py >> 7), (uint32_t)(px >> 7), (uint32_t)(frame_index >> 8));
+    uint32_t yoff = orc_hash3((uint32_t)(px >> 7), (uint32_t)(py >> 7), (uint32_t)(frame_index >> 8));
+    uint32_t pxox = ((uint32_t)px + xoff) & 127u, pxoy = ((uint32_t)py + yoff) & 127u;
+    uint32_t sampleIndex = (uint32_t)frame_index & 255u;
+    dim &= 255u;
+    uint32_t pxv = (pxox + (pxoy << 7)) << 3;
+    uint32_t ranked = sampleIndex ^ blueTableAt(ranking, 131072u, dim + pxv);
+    uint32_t value = blueTableAt(sobol, 65536u, dim + (ranked << 8));
+    value ^= blueTableAt(scramble, 131072u, (dim & 7u) + pxv);
+    return (0.5f + (float)value) / 256.0f;
+}
+static inline float rnd(ctx_t *c, int s, int idx) {
+    if (c->blue) /* orc_trace_params::blue_noise: the next dimension of this bounce */
+        return blueSample(c->sobol, c->scramble, c->ranking, c->px, c->py, c->frame_index, (uint32_t)(10 * s + c->drawn++));
     return orc_random3((float)(c->px + s), (float)(c->py + s), c->time + seedAt(c->oob_seeds, idx));
 }
 static inline void randvec2(ctx_t *c, int s, float *a, float *b) {
@@ -556,6 +576,7 @@ static void tracePath(ctx_t *c, v3 origin, v3 dir, v3 invdir, int maxBounces, pa
         if (!found || bounces >= maxBounces) break;
 
         origin = vadd(SI.point, vscale(SI.normal, EPSILON_F));
+        c->drawn = 0; /* (blue-noise mode: the bounce's numbers are dimensions 10 * bounces + 0 .. 9) */
         v3 Ld = UniformSampleOneLight(c, origin, dir, &SI, bounces);
         if (c->weighted_lights & 2) { L = Ld; break; } /* pick probe: the path's colour is the first pick */
         L = vadd(L, vmul(beta, Ld));
@@ -603,6 +624,11 @@ void orc_trace(const orc_scene *scene, const orc_trace_params *p, float *color, 
             c.num_emitters_uniform = p->num_emitters;
             c.weighted_lights = p->weighted_lights;
             memcpy(c.oob_seeds, p->oob_seeds, sizeof c.oob_seeds);
+            c.blue = p->blue_noise != 0;
+            c.frame_index = p->frame_index;
+            c.sobol = p->sobol;
+            c.scramble = p->scramble;
+            c.ranking = p->ranking;
             /* trace3.cs:805-807 */
             float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
             v3 dir = normalize3(mix3(mix3(r00, r01, pyf), mix3(r10, r11, pyf), pxf));
@@ -982,19 +1008,9 @@ typedef struct {
 } actx_t;
 
 /* trace1.cs:201-213; out-of-range table reads give 0 (the last pixels' entries for dimensions >= 8) */
-static inline uint32_t tableAt(const uint8_t *t, uint32_t n, uint32_t i) { return (t && i < n) ? t[i] : 0u; }
-static float sampleBlueNoise(const actx_t *c, uint32_t dim) {
+static float sampleBlueNoise(const actx_t *c, uint32_t dim) { /* trace1.cs:201-213: blueSample above */
     const orc_analytic_params *p = c->p;
-    uint32_t xoff = orc_hash3((uint32_t)(c->py >> 7), (uint32_t)(c->px >> 7), (uint32_t)(p->frame_index >> 8));
-    uint32_t yoff = orc_hash3((uint32_t)(c->px >> 7), (uint32_t)(c->py >> 7), (uint32_t)(p->frame_index >> 8));
-    uint32_t pxox = ((uint32_t)c->px + xoff) & 127u, pxoy = ((uint32_t)c->py + yoff) & 127u;
-    uint32_t sampleIndex = (uint32_t)p->frame_index & 255u;
-    dim &= 255u;
-    uint32_t pxv = (pxox + (pxoy << 7)) << 3;
-    uint32_t ranked = sampleIndex ^ tableAt(p->ranking, 131072u, dim + pxv);
-    uint32_t value = tableAt(p->sobol, 65536u, dim + (ranked << 8));
-    value ^= tableAt(p->scramble, 131072u, (dim & 7u) + pxv);
-    return (0.5f + (float)value) / 256.0f;
+    return blueSample(p->sobol, p->scramble, p->ranking, c->px, c->py, p->frame_index, dim);
 }
 
 static void randvec3_analytic(const actx_t *c, int kernel, int s, float *a, float *b, float *d) {

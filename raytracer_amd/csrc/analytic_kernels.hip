@@ -149,22 +149,10 @@ struct PixelOut {
     int id;
 };
 
-// sampleBlueNoise, trace1.cs:201-213.  Reads past a table's end give 0, as on the reference's platform
-// (dimensions 8..14 of the last pixels of the 128x128 tile index beyond the 131072-byte ranking table).
-__device__ __forceinline__ uint32_t tableAt(const uint8_t *__restrict__ t, uint32_t n, uint32_t i) {
-    return i < n ? (uint32_t)t[i] : 0u;
-}
+// sampleBlueNoise, trace1.cs:201-213 (trace3_device.h: sampleBlueNoiseT)
 __device__ __forceinline__ float sampleBlueNoise(const AnalyticTables &tb, int px, int py, int frameIndex, uint32_t dim) {
-    const uint32_t xoff = hash3((uint32_t)(py >> 7), (uint32_t)(px >> 7), (uint32_t)(frameIndex >> 8));
-    const uint32_t yoff = hash3((uint32_t)(px >> 7), (uint32_t)(py >> 7), (uint32_t)(frameIndex >> 8));
-    const uint32_t ox = ((uint32_t)px + xoff) & 127u, oy = ((uint32_t)py + yoff) & 127u;
-    const uint32_t sampleIndex = (uint32_t)frameIndex & 255u;
-    dim &= 255u;
-    const uint32_t pxv = (ox + (oy << 7)) << 3;
-    const uint32_t ranked = sampleIndex ^ tableAt(tb.ranking, 131072u, dim + pxv);
-    uint32_t value = tableAt(tb.sobol, 65536u, dim + (ranked << 8));
-    value ^= tableAt(tb.scramble, 131072u, (dim & 7u) + pxv);
-    return (0.5f + (float)value) / 256.0f;
+    const RtBlueTables t = {tb.sobol, tb.scramble, tb.ranking};
+    return sampleBlueNoiseT(t, px, py, frameIndex, dim);
 }
 
 // trace(), trace.cs:138-250

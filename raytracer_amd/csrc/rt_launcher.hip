@@ -19,7 +19,7 @@
 #include "wavefront.h"
 
 hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace_params &p, const rt_rect &tile,
-                          int xcdRemap, RtCountersDev *counters, hipStream_t stream);
+                          int xcdRemap, RtCountersDev *counters, hipStream_t stream, const RtBlueTablesHost *blueHost);
 // Called by the wavefront launcher between its kernels when profiling is on.
 struct rt_ctx;
 void rtMarkKernel(void *ctxOpaque, int kind, bool begin);
@@ -815,7 +815,10 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         wp.s[k].oob0 = params[k].oobSeeds[0];
         wp.s[k].oob1 = params[k].oobSeeds[1];
         wp.s[k].oob2 = params[k].oobSeeds[2];
+        wp.s[k].frameIndex = params[k].frameIndex;
     }
+    const RtBlueTablesHost blue = {(const uint8_t *)c->tables[RT_TABLE_SOBOL].p, (const uint8_t *)c->tables[RT_TABLE_SCRAMBLE].p,
+                                   (const uint8_t *)c->tables[RT_TABLE_RANKING].p};
     const bool timeIt = tuning && (wt.state == 1 || wt.state == 2);
     if (timeIt) {
         if (!wt.ev[0]) wt.ev[0] = takeEvent(c);
@@ -839,7 +842,7 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     SpanGuard span(spanCtx, TK_TRACE, profiled);
     WfScheduleOut chosen = {};
     hipError_t e = rtLaunchWavefront(sc, img, wp, wf, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream, beforeCommit,
-                                     profiled ? c : nullptr, predicted, &chosen);
+                                     profiled ? c : nullptr, predicted, &chosen, &blue);
     span.end();
     {
         rt_schedule_info &si = c->lastSchedule;
@@ -910,6 +913,9 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         if (tilePixels == 0) return RT_OK;
         if ((p->flags & RT_FLAG_WATERTIGHT) && (p->flags & RT_FLAG_FAST_SHADOWS))
             return fail(c, RT_EINVAL, "rt_trace: RT_FLAG_WATERTIGHT and RT_FLAG_FAST_SHADOWS cannot be combined");
+        if ((p->flags & RT_FLAG_BLUE_NOISE) &&
+            (!c->tables[RT_TABLE_SOBOL].p || !c->tables[RT_TABLE_SCRAMBLE].p || !c->tables[RT_TABLE_RANKING].p))
+            return fail(c, RT_ESTATE, "rt_trace: RT_FLAG_BLUE_NOISE needs the sobol, scramble and ranking tables (rt_set_table)");
         const bool perPixel = (p->flags & RT_FLAG_PER_PIXEL_KERNEL) || p->maxBounces > 30 ||
                               tilePixels * (size_t)n > ((size_t)1 << 30);
         if (perPixel) {
@@ -919,7 +925,9 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
                 SpanGuard span(c, TK_TRACE), span2(c, RT_TIME_PER_PIXEL);
                 rt_trace_params pk = params[k];
                 pk.maxFollows = std::min(pk.maxFollows > 0 ? pk.maxFollows : 1000, std::max(c->numNodes, 1)); // see wavefrontFrame
-                hipError_t e = rtLaunchTrace3(sc, img, pk, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream);
+                const RtBlueTablesHost blue = {(const uint8_t *)c->tables[RT_TABLE_SOBOL].p, (const uint8_t *)c->tables[RT_TABLE_SCRAMBLE].p,
+                                               (const uint8_t *)c->tables[RT_TABLE_RANKING].p};
+                hipError_t e = rtLaunchTrace3(sc, img, pk, r, xcdRemap, (RtCountersDev *)c->counters.p, c->stream, &blue);
                 span2.end();
                 span.end();
                 if (e != hipSuccess) return hipFail(c, e, "trace3 launch");
@@ -1100,6 +1108,9 @@ int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const
     if (p->maxBounces < 0 || p->maxBounces > 30) return fail(c, RT_EINVAL, "rt_trace_batch_static: maxBounces must be 0..30");
     if ((p->flags & RT_FLAG_WATERTIGHT) && (p->flags & RT_FLAG_FAST_SHADOWS))
         return fail(c, RT_EINVAL, "rt_trace: RT_FLAG_WATERTIGHT and RT_FLAG_FAST_SHADOWS cannot be combined");
+    if ((p->flags & RT_FLAG_BLUE_NOISE) &&
+        (!c->tables[RT_TABLE_SOBOL].p || !c->tables[RT_TABLE_SCRAMBLE].p || !c->tables[RT_TABLE_RANKING].p))
+        return fail(c, RT_ESTATE, "rt_trace_batch_static: RT_FLAG_BLUE_NOISE needs the sobol, scramble and ranking tables (rt_set_table)");
     if (!c->boxes.p || !c->tris48.p || !c->mtls.p)
         return fail(c, RT_ESTATE, "rt_trace_batch_static: nodes, triangles and materials must be uploaded first");
     if (c->maxTriEnd > c->numTris)

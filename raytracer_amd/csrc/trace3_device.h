@@ -16,12 +16,20 @@ namespace {
 #define EPSILON_F 0.0001f
 #define SPECULARITY 0.5f
 
+struct RtBlueTables { // RT_FLAG_BLUE_NOISE: the three byte tables of the blue-noise Sobol sampler (rt_set_table)
+    const uint8_t *sobol, *scramble, *ranking;
+};
+
 struct PathCtx {
     int px, py;
     float time;
     int seed;
     float oob0, oob1, oob2;
     int maxFollows;
+    // RT_FLAG_BLUE_NOISE (a compile-time constant of the kernels that set it: the white-noise kernels carry none of this)
+    bool blue;
+    int frameIndex, drawn; // sample index of the sampler; numbers drawn so far at this bounce
+    RtBlueTables tables;
     // counters
     unsigned rays, visits, tests, shaded;
     int lastIterations;
@@ -71,16 +79,41 @@ __device__ __forceinline__ float seedAt(const PathCtx &c, int i) {
     const float r = b3 ? g1 : g0;
     return k < 16u ? r : 0.0f;
 }
-__device__ __forceinline__ float rnd(const PathCtx &c, int s, int idx) {
+// sampleBlueNoise, trace1.cs:201-213.  Reads past a table's end give 0, as on the reference's platform
+// (dimensions 8..14 of the last pixels of the 128x128 tile index beyond the 131072-byte ranking table).
+__device__ __forceinline__ uint32_t blueTableAt(const uint8_t *__restrict__ t, uint32_t n, uint32_t i) {
+    return i < n ? (uint32_t)t[i] : 0u;
+}
+__device__ __forceinline__ float sampleBlueNoiseT(const RtBlueTables &tb, int px, int py, int frameIndex, uint32_t dim) {
+    const uint32_t xoff = hash3((uint32_t)(py >> 7), (uint32_t)(px >> 7), (uint32_t)(frameIndex >> 8));
+    const uint32_t yoff = hash3((uint32_t)(px >> 7), (uint32_t)(py >> 7), (uint32_t)(frameIndex >> 8));
+    const uint32_t ox = ((uint32_t)px + xoff) & 127u, oy = ((uint32_t)py + yoff) & 127u;
+    const uint32_t sampleIndex = (uint32_t)frameIndex & 255u;
+    dim &= 255u;
+    const uint32_t pxv = (ox + (oy << 7)) << 3;
+    const uint32_t ranked = sampleIndex ^ blueTableAt(tb.ranking, 131072u, dim + pxv);
+    uint32_t value = blueTableAt(tb.sobol, 65536u, dim + (ranked << 8));
+    value ^= blueTableAt(tb.scramble, 131072u, (dim & 7u) + pxv);
+    return (0.5f + (float)value) / 256.0f;
+}
+// One random number of bounce s.  RT_FLAG_BLUE_NOISE (not a mode of the reference's trace3.cs; include/rt_launcher.h): the
+// k-th number drawn at a bounce is dimension 10 * s + k of the blue-noise sampler instead of the hash of trace3.cs:280-301.
+__device__ __forceinline__ float rnd(PathCtx &c, int s, int idx) {
+    if (c.blue) return sampleBlueNoiseT(c.tables, c.px, c.py, c.frameIndex, (uint32_t)(10 * s + c.drawn++));
     return random3((float)(c.px + s), (float)(c.py + s), c.time + seedAt(c, idx));
 }
 __device__ __forceinline__ float2 randvec2(PathCtx &c, int s) { // trace3.cs:283-288
     c.seed = (c.seed + 2) % 13;
-    return make_float2(rnd(c, s, c.seed - 2), rnd(c, s, c.seed - 1));
+    const float a = rnd(c, s, c.seed - 2); // (in this order: the blue-noise mode numbers its draws)
+    const float b = rnd(c, s, c.seed - 1);
+    return make_float2(a, b);
 }
 __device__ __forceinline__ f3 randvec3(PathCtx &c, int s) { // trace3.cs:290-296
     c.seed = (c.seed + 3) % 13;
-    return F3(rnd(c, s, c.seed - 3), rnd(c, s, c.seed - 2), rnd(c, s, c.seed - 1));
+    const float a = rnd(c, s, c.seed - 3);
+    const float b = rnd(c, s, c.seed - 2);
+    const float d = rnd(c, s, c.seed - 1);
+    return F3(a, b, d);
 }
 __device__ __forceinline__ float randfloat(PathCtx &c, int s) { // trace3.cs:298-301
     c.seed = (c.seed + 1) % 13;

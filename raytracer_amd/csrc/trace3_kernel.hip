@@ -20,11 +20,12 @@
 //    reductions and issued as one atomic per wave and counter.
 #define RT_DEBUG_WALK_EXPORT rt_debug_walk_violations_per_pixel
 #include "trace3_device.h"
+#include "wavefront.h"
 
-template <bool WATERTIGHT, int NODES>
+template <bool WATERTIGHT, int NODES, bool BLUE>
 __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img, rt_trace_params p, rt_rect tile,
                                                         int tilesX, int tilesY, int xcdRemap,
-                                                        RtCountersDev *counters) {
+                                                        RtCountersDev *counters, RtBlueTables blue) {
     // Tile order.  Blocks b, b+8, b+16, ... share an XCD (and its private L2).  When the scene is larger
     // than an L2, those blocks get consecutive tiles so that each L2 caches one screen region's part of
     // the BVH; when the whole scene fits in every L2 the plain order is kept, which spreads the
@@ -51,6 +52,10 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
     c.maxFollows = p.maxFollows > 0 ? p.maxFollows : 1000;
     c.rays = c.visits = c.tests = c.shaded = 0;
     c.lastIterations = 0;
+    c.blue = BLUE; // RT_FLAG_BLUE_NOISE (trace3_device.h: rnd)
+    c.frameIndex = p.frameIndex;
+    c.drawn = 0;
+    c.tables = blue;
     unsigned primaryVisits = 0, primaryTests = 0;
     fillNodeCache(sc, sc.boxes); // the top of the tree (all of it for the named scenes) in LDS: trace3_device.h, loadNodeT
 
@@ -92,6 +97,7 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
             if (!found || bounces >= p.maxBounces) break;
 
             origin = SI.point + SI.normal * EPSILON_F;
+            c.drawn = 0; // (blue-noise mode: this bounce's numbers are dimensions 10 * bounces + 0 .. 9)
 
             float light_prob;
             const int li = pickLight(sc, c, bounces, p.numEmitters, (p.flags & RT_FLAG_WEIGHTED_LIGHTS) != 0, origin, light_prob);
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256) void rt_trace3_kernel(RtScene sc, RtImages img
 
 // Host-side launch used by rt_launcher.hip
 hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace_params &p, const rt_rect &tile,
-                          int xcdRemap, RtCountersDev *counters, hipStream_t stream) {
+                          int xcdRemap, RtCountersDev *counters, hipStream_t stream, const RtBlueTablesHost *blueHost) {
     const int tw = tile.x1 - tile.x0, th = tile.y1 - tile.y0;
     if (tw <= 0 || th <= 0) return hipSuccess;
     const int tilesX = (tw + 15) / 16, tilesY = (th + 15) / 16;
@@ -148,10 +154,15 @@ hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace
     // the walk's node fetch, decided here for the scene as uploaded (trace3_device.h: traverse)
     const bool wt = (p.flags & RT_FLAG_WATERTIGHT) != 0;
     const int nodes = rtNodeFetchFor(cached, cached.cacheNodes);
-    auto kernel = nodes == NODES_PLAIN ? (wt ? rt_trace3_kernel<true, NODES_PLAIN> : rt_trace3_kernel<false, NODES_PLAIN>)
-                  : nodes == NODES_PACKED_LDS ? (wt ? rt_trace3_kernel<true, NODES_PACKED_LDS> : rt_trace3_kernel<false, NODES_PACKED_LDS>)
-                                              : (wt ? rt_trace3_kernel<true, NODES_PACKED> : rt_trace3_kernel<false, NODES_PACKED>);
+    const bool useBlue = (p.flags & RT_FLAG_BLUE_NOISE) != 0 && blueHost;
+    const RtBlueTables blue = useBlue ? RtBlueTables{blueHost->sobol, blueHost->scramble, blueHost->ranking}
+                                      : RtBlueTables{nullptr, nullptr, nullptr};
+#define RT_PP(WT_, N_) (useBlue ? rt_trace3_kernel<WT_, N_, true> : rt_trace3_kernel<WT_, N_, false>)
+    auto kernel = nodes == NODES_PLAIN ? (wt ? RT_PP(true, NODES_PLAIN) : RT_PP(false, NODES_PLAIN))
+                  : nodes == NODES_PACKED_LDS ? (wt ? RT_PP(true, NODES_PACKED_LDS) : RT_PP(false, NODES_PACKED_LDS))
+                                              : (wt ? RT_PP(true, NODES_PACKED) : RT_PP(false, NODES_PACKED));
+#undef RT_PP
     hipLaunchKernelGGL(kernel, dim3(nblocks), dim3(256), (size_t)cached.cacheNodes * 32, stream, cached, img, p, tile, tilesX,
-                       tilesY, xcdRemap, counters);
+                       tilesY, xcdRemap, counters, blue);
     return hipGetLastError();
 }

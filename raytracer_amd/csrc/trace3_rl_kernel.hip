@@ -360,6 +360,10 @@ __global__ __launch_bounds__(256) void rt_trace3_rl_kernel(RtScene sc, RtQTable 
     c.maxFollows = p.maxFollows > 0 ? p.maxFollows : 1000;
     c.rays = c.visits = c.tests = c.shaded = 0;
     c.lastIterations = 0;
+    c.blue = false; // (RT_FLAG_BLUE_NOISE is a mode of trace() only)
+    c.frameIndex = 0;
+    c.drawn = 0;
+    c.tables = RtBlueTables{nullptr, nullptr, nullptr};
     unsigned updates = 0, primaryVisits = 0, primaryTests = 0;
     fillNodeCache(sc, sc.boxes); // the top of the tree (all of it for the named scenes) in LDS: trace3_device.h, loadNodeT
 

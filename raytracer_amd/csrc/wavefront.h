@@ -8,6 +8,7 @@
 
 struct WfSample { // per-sample uniforms of a batch (what differs between successive Tracer::trace calls)
     float time, blendFactor, oob0, oob1, oob2;
+    int frameIndex; // RT_FLAG_BLUE_NOISE: the sampler's sample index
 };
 
 struct WfParams {
@@ -74,13 +75,18 @@ struct WfScheduleOut { // what rtLaunchWavefront decided (rt_last_schedule)
     int rowsStageMask, dense, extendBlocksPerCU, nodeFetch;
 };
 
+struct RtBlueTablesHost;
 // predictedCounts: queue sizes per stage of a similar earlier frame (32 ints), or null when there is none
 // beforeCommit: an event the stream waits for before the blend kernel (the only kernel that writes caller-visible
 // images when the G-buffer is staged), or null
 hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &img, const WfParams &p, const WfBuffers &wf,
                              const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream,
                              hipEvent_t beforeCommit,
-                             void *profileCtx, const int *predictedCounts, WfScheduleOut *chosen = nullptr);
+                             void *profileCtx, const int *predictedCounts, WfScheduleOut *chosen = nullptr,
+                             const struct RtBlueTablesHost *blue = nullptr);
+struct RtBlueTablesHost { // RT_FLAG_BLUE_NOISE: device pointers of the sobol / scramble / ranking byte tables
+    const uint8_t *sobol, *scramble, *ranking;
+};
 void rtMarkKernel(void *ctxOpaque, int kind, bool begin);
 // bytes of device memory per unit of capacity (one path slot) and per (sample, tile pixel)
 size_t rtWavefrontBytesPerPath();

@@ -82,6 +82,10 @@ __device__ __forceinline__ PathCtx makeCtx(const WfParams &p, int x, int y, int 
     c.maxFollows = p.maxFollows;
     c.rays = c.visits = c.tests = c.shaded = 0;
     c.lastIterations = 0;
+    c.blue = false;
+    c.frameIndex = p.s[sample].frameIndex;
+    c.drawn = 0;
+    c.tables = RtBlueTables{nullptr, nullptr, nullptr};
     return c;
 }
 
@@ -194,8 +198,10 @@ __device__ __forceinline__ float lightDistance(const LightTri &t, f3 origin, f3 
     return hi >= 0 ? ht : -1.0f;
 }
 
+// BLUE: RT_FLAG_BLUE_NOISE (a kernel of its own, so that the default one carries neither the tables nor the branch)
+template <bool BLUE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void rt_wf_logic_kernel(RtScene sc, RtImages img, WfParams p, WfBuffers wf,
-                                                          rt_rect tile, int bounce, RtCountersDev *counters) {
+                                                          rt_rect tile, int bounce, RtCountersDev *counters, RtBlueTables blue) {
     // bounce 0: the stage-0 queue holds one entry per pixel (the shared primary hit); every sample of the batch becomes
     // a path of its own here: lane i = (entry i / batch, sample i % batch), path id = i
     const int n = bounce == 0 ? min(wf.counts[0] * p.batch, wf.capacity) : min(wf.counts[bounce], wf.capacity);
@@ -315,6 +321,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         if (requeue) {
             const int x = pix % W, y = pix / W;
             PathCtx c = makeCtx(p, x, y, sample, seed);
+            if (BLUE) { // all ten numbers of this bounce are drawn below: dimensions 10 * bounce + 0 .. 9
+                c.blue = true;
+                c.tables = blue;
+            }
             const RtMtl m = fetchMtl(sc, SI.matidx);
             float4 *outO = wf.rayO[(bounce + 1) & 1], *outD = wf.rayD[(bounce + 1) & 1];
             const f3 o2 = SI.point + SI.normal * EPSILON_F;
@@ -1243,7 +1253,8 @@ size_t rtWavefrontBytesPerPath() { return 2 * (6 * 16 + 8 + 16) + 3 * (4 * 16 + 
 
 hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const WfParams &p, const WfBuffers &wf,
                              const rt_rect &tile, int xcdRemap, RtCountersDev *counters, hipStream_t stream,
-                             hipEvent_t beforeCommit, void *prof, const int *predictedCounts, WfScheduleOut *chosen) {
+                             hipEvent_t beforeCommit, void *prof, const int *predictedCounts, WfScheduleOut *chosen,
+                             const RtBlueTablesHost *blueHost) {
     const int tw = tile.x1 - tile.x0, th = tile.y1 - tile.y0;
     if (tw <= 0 || th <= 0 || p.batch <= 0) return hipSuccess;
     RtImages img = imgOut; // what the kernels before the blend write: the staged G-buffer when there is one
@@ -1269,6 +1280,10 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
 
     // persistent grids: enough resident waves to fill the chip, independent of the (device-side) queue size
     const int logicBlocks = 256 * 4;
+    const bool useBlue = (p.flags & RT_FLAG_BLUE_NOISE) != 0 && blueHost;
+    const RtBlueTables blue = useBlue ? RtBlueTables{blueHost->sobol, blueHost->scramble, blueHost->ranking}
+                                      : RtBlueTables{nullptr, nullptr, nullptr};
+    auto logicKernel = useBlue ? rt_wf_logic_kernel<true> : rt_wf_logic_kernel<false>;
     // the walk's node fetch is chosen here, once per launch (trace3_device.h: loadNodeT)
     const int extendNodes = !sc.packedLeaves ? NODES_PLAIN : scExtend.cacheNodes >= sc.numNodes ? NODES_PACKED_LDS : NODES_PACKED;
     // two triangles per test on packed fp32 (the pair stream): only where its smaller records pay, beyond the L2s
@@ -1319,7 +1334,7 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
     extend(0);
     for (int b = 0; b <= p.maxBounces; ++b) {
         if (prof) rtMarkKernel(prof, RT_TIME_WF_LOGIC, true);
-        hipLaunchKernelGGL(rt_wf_logic_kernel, dim3(logicBlocks), dim3(256), 0, stream, scPlain, img, p, wf, tile, b, counters);
+        hipLaunchKernelGGL(logicKernel, dim3(logicBlocks), dim3(256), 0, stream, scPlain, img, p, wf, tile, b, counters, blue);
         if (prof) rtMarkKernel(prof, RT_TIME_WF_LOGIC, false);
         if (b < p.maxBounces) extend(b + 1);
     }

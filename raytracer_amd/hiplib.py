@@ -15,6 +15,7 @@ COMM_ID_BYTES = 128
 KERNEL_TRACE3, KERNEL_TRACE3_RL, KERNEL_TRACE, KERNEL_TRACE1, KERNEL_TRACE2 = range(5)
 FLAG_AUX, FLAG_PIXEL_STATS, FLAG_NO_COUNTERS, FLAG_PER_PIXEL_KERNEL, FLAG_FAST_SHADOWS, FLAG_WATERTIGHT = 1, 2, 4, 8, 16, 32
 FLAG_WEIGHTED_LIGHTS = 64
+FLAG_BLUE_NOISE = 128
 MAX_BATCH = 16
 TABLE_SOBOL, TABLE_SCRAMBLE, TABLE_RANKING, TABLE_LTC1, TABLE_LTC2 = range(5)
 

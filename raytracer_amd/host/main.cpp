@@ -3,6 +3,7 @@
 //   rt_headless scene.obj [--size WxH] [--frames N] [--bounces B] [--filter ITERS] [--exposure E]
 //               [--auto-camera] [--light] [--out PREFIX] [--res DIR] [--kernel trace3|trace|trace1|trace2]
 //               [--keys "FRAME:KEY,FRAME:KEY,..."] [--reset-at FRAME] [--freeze-time] [--dump-raw PREFIX] [--gpus N]
+//               [--watertight] [--fast-shadows] [--weighted-lights] [--blue-noise]   (opt-in variants, include/rt_launcher.h)
 // --kernel selects one of the reference's other kernels (its analytic box scenes; the obj file is still loaded,
 // as the reference's main does, but not traced); trace1 / trace2 read their tables from --res (default "res").
 // --keys feeds the reference's input handler (glfw_setter.hpp) before the given frame of the loop: W A S D Z X move the
@@ -159,7 +160,7 @@ void renderOn(Shared &sh, int rank, int nranks) {
                             : Tracer(&camera, &framebuffer, sh.bvh, sh.qt,
                                      std::vector<const char *>{main_cs.c_str(), "src/shaders/random.glsl"});
         tracer.resourceDir = o.res;
-        if (o.kernel == "trace1") tracer.genBlueNoiseBuffers();
+        if (o.kernel == "trace1" || (o.launchFlags & RT_FLAG_BLUE_NOISE)) tracer.genBlueNoiseBuffers();
         if (o.kernel == "trace2") tracer.genLtcData();
         tracer.launchFlags = o.launchFlags;
         tracer.maxFollows = o.maxFollows;
@@ -275,6 +276,7 @@ int main(int argc, char **argv) {
         else if (a == "--watertight") o.launchFlags |= RT_FLAG_WATERTIGHT;      // opt-in variants, not the reference's algorithm
         else if (a == "--fast-shadows") o.launchFlags |= RT_FLAG_FAST_SHADOWS;
         else if (a == "--weighted-lights") o.launchFlags |= RT_FLAG_WEIGHTED_LIGHTS;
+        else if (a == "--blue-noise") o.launchFlags |= RT_FLAG_BLUE_NOISE; // trace3 on the blue-noise sampler (tables from --res)
         else if (a == "--max-follows") o.maxFollows = std::atoi(next());
         else if (a == "--reset-at") o.resetAt = std::atoi(next());
         else if (a == "--freeze-time") o.freezeTime = true;

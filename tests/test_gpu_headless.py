@@ -177,3 +177,20 @@ def test_headless_exits_nonzero_when_a_gpu_thread_fails(tmp_path):
     r = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, timeout=90)
     assert r.returncode == 1, (r.returncode, r.stderr[-1500:])
     assert "NO USABLE GPU (rt_create(1)" in r.stderr and "gpu 1:" in r.stderr
+
+
+def test_headless_blue_noise_flag(tmp_path):
+    """rt_headless --blue-noise: Tracer::genBlueNoiseBuffers (reference src/Tracer.cpp:50-90) loads the three tables from
+    --res, launchFlags carries RT_FLAG_BLUE_NOISE, frameIndex = frameNumber: the frames of the ctypes-driven oracle check."""
+    W, H = 96, 64
+    res = os.path.dirname(assets.path("ltc1.data"))
+    for t in workloads.TABLE_FILES.values():
+        assets.path(t)
+    prefix, _ = run_headless(tmp_path, "room.obj", "--size", f"{W}x{H}", "--frames", 3, "--bounces", 4, "--blue-noise", "--res", res)
+    got = load_dump(prefix, W, H, False)
+    from oracle import orclib
+    wl = workloads.Workload("room", W, H)
+    tables = workloads.analytic_tables()
+    ref = orclib.trace(orclib.Scene(wl.buffers), W, H, wl.rays, wl.eye, spp=3, max_bounces=4,
+                       blue_noise={k: tables[k] for k in ("sobol", "scramble", "ranking")})
+    check_against_oracle(got, ref, 0, "headless blue noise")

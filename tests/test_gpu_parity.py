@@ -538,3 +538,40 @@ def test_caller_supplied_stream(ctx):
         assert np.array_equal(got[k].view(np.uint8), ref[k].view(np.uint8)), k
     ctx.filter(3)
     assert np.array_equal(ctx.readback(hiplib.IMAGE_FILTERED).view(np.uint16), filtered)
+
+
+def test_blue_noise_flag(ctx):
+    """RT_FLAG_BLUE_NOISE (opt-in; NOT a mode of the reference's trace3.cs, so parity is unpinned by construction): trace()
+    draws from the blue-noise Sobol sampler of trace1.cs:201-213 — itself pinned by the analytic_trace1_* llvmpipe
+    fixtures — dimension 10 * bounce + k for the bounce's k-th number.  Checked against the CPU oracle's same mode, bit
+    for bit between the two schedules and the no-allocation entry point, and refused without the tables."""
+    base = hiplib.FLAG_AUX | hiplib.FLAG_PIXEL_STATS
+    tables = workloads.analytic_tables()
+    blue = {k: tables[k] for k in ("sobol", "scramble", "ranking")}
+    fresh = hiplib.Context(0)
+    try:
+        wl = workloads.Workload("room", 64, 48)
+        fresh.upload_scene(wl.buffers)
+        fresh.resize(64, 48)
+        with pytest.raises(hiplib.RtError, match="needs the sobol"):
+            fresh.trace_samples(wl.rays, wl.eye, spp=1, max_bounces=2, flags=hiplib.FLAG_BLUE_NOISE, num_emitters=wl.num_emitters)
+    finally:
+        fresh.close()
+    ctx.set_tables(blue)
+    for scene, w, h, spp, mb in (("room", 200, 150, 3, 5), ("scene", 320, 180, 4, 5), ("room", 130, 140, 2, 3)):  # (130 x 140: two sampler tiles)
+        wl = workloads.Workload(scene, w, h)
+        ref = oracle_render(wl, spp, mb, blue_noise=blue)
+        got = render(ctx, wl, spp, mb, flags=base | hiplib.FLAG_BLUE_NOISE)
+        assert_ids_equal(got, ref)
+        assert_radiance_close(ref["color"], got["color"], f"blue noise {scene} {w}x{h}")
+        white = render(ctx, wl, spp, mb, flags=base)
+        assert not np.array_equal(white["color"], got["color"])
+        assert np.array_equal(white["tridx"], got["tridx"])              # the primary ray does not depend on the sampler
+        for kw in (dict(batch=1), dict(batch=1, flags=base | hiplib.FLAG_BLUE_NOISE | hiplib.FLAG_PER_PIXEL_KERNEL)):
+            kw.setdefault("flags", base | hiplib.FLAG_BLUE_NOISE)
+            other = render(ctx, wl, spp, mb, **kw)
+            for k in ALL_IMAGES:
+                assert np.array_equal(other[k].view(np.uint8), got[k].view(np.uint8)), (scene, k, kw)
+    if wl.width * wl.height * spp <= hiplib.lib().rt_static_max_paths():
+        st = render(ctx, wl, spp, mb, flags=base | hiplib.FLAG_BLUE_NOISE, static=True)
+        assert np.array_equal(st["color"].view(np.uint8), got["color"].view(np.uint8))
