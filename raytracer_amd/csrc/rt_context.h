@@ -77,7 +77,7 @@ struct rt_ctx {
     int framesInFlight = RT_DEFAULT_LANES; // lanes in use, 1 .. RT_MAX_LANES (rt_set_frames_in_flight, RT_PIPELINE)
     bool lanesByCaller = false;         // set by rt_set_frames_in_flight / RT_PIPELINE: then used as given; else scenes beyond the L2s get 3
     int tuneExtendBlocksDense = 3;                   // ... for stages of at least 2 M rays (WfParams::extendBlocksDense)
-    int tuneRefillLanes = 0, tuneExtendBlocks = 4;  // development knobs: RT_WF_REFILL (0: by scene size), RT_WF_BLOCKS
+    int tuneRefillLanes = 0, tuneExtendBlocks = 0;  // development knobs: RT_WF_REFILL (0: by scene size), RT_WF_BLOCKS (0: 4 alone, 2 with frames in flight)
     bool packedLeaves = false;                       // node records carry the leaf range (rt_device.h)
     int tuneWalkStop = 0, tuneWalkMin = 0;           // RT_WF_WALK_STOP (eighths), RT_WF_WALK_MIN: 0 = by scene size (WfParams::walkStop)
     // L2-resident scenes: whether full waves should cut their walk phases short depends on the scene (room.obj

@@ -754,8 +754,15 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     // a wave takes new rays when all its lanes are free (neighbouring rays stay together: vector-L1 locality) —
     // or, when the scene is beyond the L2s and there is no locality to keep, as soon as half of them are
     wp.refillLanes = c->tuneRefillLanes > 0 ? c->tuneRefillLanes : (hot > (size_t)3 * 1024 * 1024 ? 32 : 64);
-    wp.extendBlocksPerCU = c->tuneExtendBlocks;
-    wp.rowMode = c->tuneRowMode >= 0 ? c->tuneRowMode : 2;
+    // Persistent extend blocks per CU and row mode depend on whether the frame shares the GPU (round 3, metric frame with
+    // four frames in flight, scripts/knob_bench.sh): 4 blocks + row mode 0.877-0.885 ms per frame, 2 blocks + row mode
+    // 0.846, 2 blocks and no row mode 0.822-0.826 (3 blocks: 0.849, 1 block: 0.873).  An extend block holds 31-40 KB of LDS
+    // (node cache + wave scratch): four per CU fill the CU's 160 KB, so another frame's extend kernel can only start as
+    // this one's blocks drain; with two, two frames' extend kernels are resident side by side, and row mode — 16 lanes
+    // per ray, a latency device — only spends issue slots the other frames could use.  A frame on its own keeps four
+    // blocks and row mode (1.61 ms; 1.98 ms with the in-flight setting).
+    wp.extendBlocksPerCU = c->tuneExtendBlocks > 0 ? c->tuneExtendBlocks : (beforeCommit ? 2 : 4);
+    wp.rowMode = c->tuneRowMode >= 0 ? c->tuneRowMode : (beforeCommit ? 0 : 2);
     wp.rowMaxRays = c->tuneRowMaxRays >= 0 ? c->tuneRowMaxRays : 65536;
     wp.longWalk = c->tuneLongWalk;
     wp.extendPairs = c->tunePairs;
@@ -801,7 +808,7 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     // (the frames that time the schedule candidates must not differ in anything else)
     // (three blocks per CU pay when several frames share the GPU — room.obj 33.3 -> 32.2 ms with four in flight —; a frame
     // that has it to itself wants the four: 4.75 against 5.53 ms per dense extend launch)
-    wp.extendBlocksDense = (settled && beforeCommit) ? c->tuneExtendBlocksDense : c->tuneExtendBlocks;
+    wp.extendBlocksDense = (settled && beforeCommit) ? c->tuneExtendBlocksDense : (c->tuneExtendBlocks > 0 ? c->tuneExtendBlocks : 4);
     wp.extendChunk = c->tuneChunk;
     // full waves test their leaves cooperatively when the triangles do not fit the L2s (measured on MI355X: the
     // coalesced triangle reads of that scheme win on the 1.7 M-triangle lattice, 3.66 -> 3.28 ms, and lose to

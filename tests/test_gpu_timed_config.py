@@ -4,8 +4,9 @@ tests/test_gpu_parity.py renders through `render()`: a fresh rt_resize (no queue
 side images (RT_FLAG_AUX | RT_FLAG_PIXEL_STATS: frames in flight off).  That leaves out what a run of frames uses:
   * rt_wf_extend_rows_kernel (one ray per 16-lane row, speculative four-decision walk, DPP row minimum) — chosen per
     stage from the previous frame's queue sizes, or for every stage with RT_WF_ROWS=1;
-  * flags 0, four frames in flight on four lanes with staged G-buffers, fill 1, the flat-cell record in the filter,
-    three extend blocks per CU on dense frames.
+  * flags 0, four frames in flight on four lanes with staged G-buffers, fill 1, two extend blocks per CU and no row
+    mode (three blocks on dense frames), the flat-cell record in the filter; and, one frame at a time, four blocks
+    per CU with the sparse stages in the row-mode kernel by prediction.
 Here both are compared with the CPU oracle (oracle/rt_oracle.c, pinned by the llvmpipe fixtures) and the llvmpipe
 fixtures directly, and rt_last_schedule / the rows_* counters assert that those kernels really ran.
 Visit order to match: reference src/shaders/trace3.cs:216-278."""
@@ -160,7 +161,7 @@ def test_row_mode_max_follows_abort(rows, lanes, max_follows):
 
 
 # ------------------------------------------------------------------------------------------------ (b), (c) bench shape
-def bench_shape(scene, frames, want_dense):
+def bench_shape(scene, frames, want_dense, in_flight_setting=0):
     """bench.py's timed region: rt_trace_batch (4 samples, flags 0) + rt_filter(5) per frame, queued back to back without
     a sync, after the launcher has settled its schedule — here with frames that ACCUMULATE (sample index keeps counting,
     so frame k blends onto frame k-1's colour across lanes), compared with the oracle's 4 * frames samples."""
@@ -171,6 +172,8 @@ def bench_shape(scene, frames, want_dense):
     try:
         ctx.upload_scene(wl.buffers)
         ctx.resize(W, H)
+        if in_flight_setting:
+            ctx.set_frames_in_flight(in_flight_setting)
 
         def frame(k):
             ctx.trace_samples(wl.rays, wl.eye, spp=spp, frame0=spp * k, max_bounces=mb, flags=0, num_emitters=wl.num_emitters)
@@ -208,18 +211,22 @@ def bench_shape(scene, frames, want_dense):
     finally:
         ctx.close()
     # --- the schedule that ran is the timed one
-    assert in_flight == 4
+    alone = in_flight_setting == 1
+    assert in_flight == (1 if alone else 4)
     for s in schedules:
-        assert s["pipelined"] == 1 and s["frames_in_flight"] == 4 and s["walk_settled"] == 1, s
-        assert s["have_prediction"] == 1 and s["fill"] == 1 and s["flat_record"] == 1 and s["node_fetch"] == 2, s
+        assert s["walk_settled"] == 1 and s["have_prediction"] == 1 and s["flat_record"] == 1 and s["node_fetch"] == 2, s
         assert s["stages"] == mb + 1
-        if want_dense:
-            assert s["dense"] == 1 and s["extend_blocks_per_cu"] == 3, s
-        else:
-            assert s["dense"] == 0 and s["extend_blocks_per_cu"] == 4 and s["rows_stage_mask"] != 0, s
-    assert sorted({s["lane"] for s in schedules}) == list(range(min(4, frames)))
-    if not want_dense:
+        if alone:   # one frame at a time: four extend blocks per CU, sparse stages in the row-mode kernel (by prediction)
+            assert s["pipelined"] == 0 and s["frames_in_flight"] == 1 and s["fill"] == 2 and s["extend_blocks_per_cu"] == 4, s
+            assert s["dense"] == (1 if want_dense else 0) and (want_dense or s["rows_stage_mask"] != 0), s
+        else:       # frames in flight: two blocks per CU and no row mode (three blocks on dense frames)
+            assert s["pipelined"] == 1 and s["frames_in_flight"] == 4 and s["fill"] == 1 and s["rows_stage_mask"] == 0, s
+            assert (s["dense"], s["extend_blocks_per_cu"]) == ((1, 3) if want_dense else (0, 2)), s
+    assert sorted({s["lane"] for s in schedules}) == ([0] if alone else list(range(min(4, frames))))
+    if alone and not want_dense:
         assert cnt.rows_rays > 0 and cnt.rows_node_visits > 0 and cnt.rows_tri_tests > 0
+    else:
+        assert cnt.rows_rays == 0
     assert levels is not None
     # --- the picture is the oracle's
     ref = orclib.trace(orclib.Scene(wl.buffers), W, H, wl.rays, wl.eye, spp=spp * frames, max_bounces=mb)
@@ -246,6 +253,12 @@ def bench_shape(scene, frames, want_dense):
 def test_bench_shape_metric_frame_against_oracle():
     """BASELINE.json configs[2] exactly as bench.py times it: scene.obj 1920x1080, 4 spp, maxBounces 5, 5 filter passes."""
     bench_shape("scene", 6, want_dense=False)
+
+
+def test_bench_shape_one_frame_at_a_time_against_oracle():
+    """The same frames with rt_set_frames_in_flight(1) — what bench.py's latency_ms_one_frame measures: here the launcher
+    chooses the row-mode kernel for the sparse stages from the previous frame's queue sizes."""
+    bench_shape("scene", 4, want_dense=False, in_flight_setting=1)
 
 
 def test_bench_shape_dense_frame_against_oracle():
