@@ -218,10 +218,13 @@ int rt_trace_batch(rt_ctx *ctx, const rt_trace_params *params, int n, const rt_r
 /* rt_trace_batch for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  NO counterpart in the reference (its GL driver allocates behind every call).
  * Same kernels, same arguments and same images as rt_trace_batch with RT_KERNEL_TRACE3 (the wavefront pipeline), but
- * the pipeline's scratch memory — path state, ray queue, queue counters, per-sample radiance: 412 B per path slot —
- * is a fixed file-scope device array of the library (27.5 MB, held by every GPU the library runs on until the
- * process ends) instead of buffers grown with hipMalloc.  The call performs no hipMalloc / hipFree / event creation
- * and does not record profiling spans.
+ * the pipeline's scratch memory — two sets of path state, ray queue, queue counters, per-sample radiance: 508 B per
+ * path slot — is a fixed file-scope device array of the library (34.3 MB, held by every GPU the library runs on until
+ * the process ends) instead of buffers grown with hipMalloc.  The call performs no hipMalloc / hipFree, creates,
+ * records and queries no event (unless the context has had frames in flight: then its lanes are joined first, two
+ * calls per lane on events made at rt_create), copies nothing to the host and records no profiling spans: it queues
+ * memsets and kernel launches on the current stream only, so a call on a caller-supplied stream can be recorded
+ * under stream capture and replayed as a graph (tests/test_zz_no_alloc.py).
  * Limit: tile pixels x n <= rt_static_max_paths() (65 536 path slots, e.g. a 256 x 256 tile at 1 sample or 128 x 128
  * at 4); larger requests fail with RT_EINVAL and a message naming the limit.  RT_FLAG_PER_PIXEL_KERNEL and kernels
  * other than RT_KERNEL_TRACE3 are refused (they use no scratch memory: call rt_trace_batch), maxBounces <= 30.
@@ -308,7 +311,7 @@ int rt_last_schedule(const rt_ctx *ctx, rt_schedule_info *out);
  * frame k+1 is traced while frame k is still being traced / filtered, and only its last kernel, which writes colour,
  * normals and positions, waits for everything queued before the call.  The images a caller reads are the same as with
  * n = 1; what changes is the latency hidden (sparse frames leave most of the GPU idle in the tail of every stage) and
- * the memory held (412 B per pixel-sample and lane; lanes are not used when they would need more than 48 GB together).
+ * the memory held (508 B per pixel-sample and lane; lanes are not used when they would need more than 48 GB together).
  * Not used with RT_FLAG_AUX / RT_FLAG_PIXEL_STATS, on a caller-supplied stream, or while the launcher times its
  * schedule candidates.  n = 1 .. 4, or 0 for the launcher's own choice (4; 3 for scenes beyond the L2 caches, which are
  * bound by HBM and lose with a fourth frame); else RT_EINVAL.  RT_PIPELINE=n sets it at rt_create (0 or 1: one frame at a time).

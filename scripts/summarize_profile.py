@@ -31,6 +31,15 @@ if stats:
             w.writerow([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
     print("kernel stats:", len(rows), "kernels")
 
+stats1 = glob.glob(os.path.join(src, "trace1", "**", "*kernel_stats.csv"), recursive=True)
+if stats1:  # RT_PIPELINE=1: one frame at a time
+    rows = list(csv.DictReader(open(stats1[0])))
+    with open(os.path.join(dst, f"{name}_kernel_stats_one_frame_at_a_time.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ns", "average_ns", "percentage", "min_ns", "max_ns"])
+        for r in rows:
+            w.writerow([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(src, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
