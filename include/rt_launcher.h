@@ -76,7 +76,19 @@ enum rt_kernel {
     RT_KERNEL_TRACE3_RL = 1, /* trace3.cs traceRL(): Q-table guided (dead in the reference's main) */
     RT_KERNEL_TRACE = 2,  /* box-scene tracer, trace.cs                                  */
     RT_KERNEL_TRACE1 = 3, /* box scene + rect light, blue-noise sampler + 3-way MIS, trace1.cs */
-    RT_KERNEL_TRACE2 = 4  /* LTC area lights, trace2.cs                                  */
+    RT_KERNEL_TRACE2 = 4, /* LTC area lights, trace2.cs                                  */
+    /* NOT a program of the reference; "parity unpinned by construction" (the reference shades with linearly transformed
+     * cosines only in its box-room kernel, reference src/shaders/trace2.cs:163-184,244-278 - RT_KERNEL_TRACE2 here, pinned
+     * by llvmpipe fixtures).  trace2.cs's shading on the uploaded BVH scene: the primary ray of trace3.cs (:805-807) walks
+     * the BVH (:216-278); the rectangles of rt_set_rect_lights are intersected as trace2.cs:189-194 does, the nearer of
+     * geometry and rectangle wins and a rectangle shows as (1,1,1) (:251-255); a geometry hit is shaded as :262-277
+     * shades a box - both LUTs (rt_set_table RT_TABLE_LTC1 / LTC2; RT_ESTATE without them) at (params.roughness,
+     * sqrt(1 - N.V)), the LTC integral summed over the rectangles, times the hit material's Kd and the intensity - plus
+     * Ke * 30 for an emitting material (trace3.cs:632); a ray that hits nothing gets trace3's sky.  No random numbers, no
+     * accumulation (trace2.cs:289-290 stores the colour as is): every entry of a batch gives the same image.  G-buffer as
+     * trace3's write().  RT_FLAG_AUX ids: triangle index, -2 - i for rectangle i, -1 for the sky.  Flags other than AUX /
+     * PIXEL_STATS / NO_COUNTERS are refused.  Checked against the CPU oracle's same mode (orc_trace_ltc). */
+    RT_KERNEL_TRACE3_LTC = 5
 };
 
 enum rt_flags {
@@ -196,6 +208,15 @@ int rt_set_stream(rt_ctx *ctx, void *hip_stream);
  * (links and ranges in bounds) and re-packed privately into aligned device records. */
 int rt_upload(rt_ctx *ctx, int slot, const void *bytes, size_t nbytes);
 int rt_set_table(rt_ctx *ctx, int table, const void *bytes, size_t nbytes);
+/* The rectangle area lights of RT_KERNEL_TRACE3_LTC: n <= RT_MAX_RECT_LIGHTS records of reference
+ * src/shaders/trace2.cs:41-45 `rectangle` (corner c, edge vectors x and y; the light is c + s x + t y, 0 <= s, t <= 1)
+ * and LIGHT_INTENSITY (:20; 6.0 there).  No counterpart call in the reference: trace2.cs holds its 16 rectangles as
+ * shader constants (:47-64).  n = 0 removes them.  RT_EINVAL for n out of range or a non-finite value. */
+#define RT_MAX_RECT_LIGHTS 64
+typedef struct rt_rect_light {
+    float c[3], x[3], y[3];
+} rt_rect_light;
+int rt_set_rect_lights(rt_ctx *ctx, const rt_rect_light *lights, int n, float intensity);
 /* Blocking copy of a Q-table slot (7..10) back to the host, e.g. the table RT_KERNEL_TRACE3_RL has learned.
  * The reference never reads its Q-table back (reference src/QTable.cpp:138-146 only uploads); the GL
  * counterpart would be glGetBufferSubData on QTable::QTableSsbo / QVisitsSsbo. */

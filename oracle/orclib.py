@@ -65,6 +65,9 @@ def lib():
         L.orc_trace.restype = None
         L.orc_trace_analytic.argtypes = [ctypes.c_int32, ctypes.POINTER(OrcAnalyticParams), vp, vp, vp, vp]
         L.orc_trace_analytic.restype = None
+        L.orc_trace_ltc.argtypes = [ctypes.POINTER(OrcScene), ctypes.POINTER(OrcAnalyticParams), vp, ctypes.c_int32,
+                                    ctypes.c_float, ctypes.c_int32, vp, vp, vp, vp, vp, vp]
+        L.orc_trace_ltc.restype = None
         L.orc_trace_rl.argtypes = [ctypes.POINTER(OrcScene), ctypes.POINTER(OrcQTable), ctypes.POINTER(OrcTraceParams),
                                    vp, vp, vp, vp]
         L.orc_trace_rl.restype = None
@@ -233,6 +236,38 @@ def trace_analytic(kernel, width, height, rays, eye, spp=1, frame0=0, time0=1.25
         L.orc_trace_analytic(ANALYTIC_KERNELS[kernel], ctypes.byref(p), color.ctypes.data, normal.ctypes.data,
                              pos.ctypes.data, objid.ctypes.data)
     return dict(color=color, normal=normal, pos=pos.view(np.float16), tridx=objid)
+
+
+def trace_ltc(scene, width, height, rays, eye, lights, tables, roughness=0.5, intensity=6.0, max_follows=1000, rect=None):
+    """orc_trace_ltc: trace2.cs's LTC shading at the primary hit of a BVH scene (not a program of the reference: see
+    rt_oracle.h).  lights: (n, 3, 3) float32 (c, x, y per rectangle); tables: {"ltc1", "ltc2": bytes}."""
+    L = lib()
+    color = np.zeros((height, width, 4), np.float32)
+    normal = np.zeros((height, width, 4), np.int8)
+    pos = np.zeros((height, width, 4), np.uint16)
+    tridx = np.full((height, width), -9, np.int32)
+    visits = np.zeros((height, width), np.int32)
+    stats = np.zeros((height, width, 4), np.int32)
+    rays = np.asarray(rays, np.float32).reshape(4, 3)
+    p = OrcAnalyticParams()
+    p.width, p.height = width, height
+    p.eye[:] = [float(np.float32(v)) for v in eye]
+    p.ray00[:], p.ray01[:], p.ray10[:], p.ray11[:] = rays[0].tolist(), rays[1].tolist(), rays[2].tolist(), rays[3].tolist()
+    p.roughness = roughness
+    keep = {}
+    for name in ("ltc1", "ltc2"):
+        a = np.frombuffer(bytes(tables[name]), np.uint8).copy()
+        if a.size != TABLE_BYTES[name]:
+            raise ValueError(f"table {name}: {a.size} bytes, expected {TABLE_BYTES[name]}")
+        keep[name] = a
+        setattr(p, name, a.ctypes.data)
+    if rect is not None:
+        p.x0, p.y0, p.x1, p.y1 = rect
+    lights = np.ascontiguousarray(np.asarray(lights, np.float32).reshape(-1, 9))
+    L.orc_trace_ltc(ctypes.byref(scene.c), ctypes.byref(p), lights.ctypes.data if len(lights) else None, len(lights),
+                    float(intensity), int(max_follows), color.ctypes.data, normal.ctypes.data, pos.ctypes.data,
+                    tridx.ctypes.data, visits.ctypes.data, stats.ctypes.data)
+    return dict(color=color, normal=normal, pos=pos.view(np.float16), tridx=tridx, visits=visits, stats=stats)
 
 
 def filter_passes(color, normal, pos, iterations, c_phi0=3.3, n_phi0=1e-2, p_phi0=5.5):

@@ -264,6 +264,7 @@ typedef struct {
     int32_t tridx;
     v3 color, normal, point;
     int32_t matidx;
+    float t; /* (not a member in the shader: the closest hit's distance, for orc_trace_ltc) */
 } SI_t; /* trace3.cs:111-119 (uv is never consumed by trace()) */
 
 typedef struct {
@@ -359,6 +360,7 @@ static void intersectGeometry(ctx_t *c, v3 origin, v3 dir, v3 invdir, SI_t *SI) 
             SI->normal = V3(1.0f, 0.0f, 1.0f);
             SI->point = V3(0, 0, 0);
             SI->matidx = 0;
+            SI->t = INFINITY;
             return;
         }
         const node_t *next = fetchNode(c, nextIdx);
@@ -405,6 +407,7 @@ static void intersectGeometry(ctx_t *c, v3 origin, v3 dir, v3 invdir, SI_t *SI) 
     SI->normal = normal;
     SI->color = color;
     SI->point = point;
+    SI->t = nearestTri;
 }
 
 /* trace3.cs:332-355 */
@@ -1325,6 +1328,90 @@ void orc_trace_analytic(int32_t kernel, const orc_analytic_params *p, float *col
                 pos[4 * i + 3] = orc_f32_to_f16_rtz(1.0f);
             }
             if (objid) objid[i] = path.id0;
+        }
+    }
+}
+
+/* LTC rectangle lights on a BVH scene: NOT a program of the reference (it shades with LTC only in trace2.cs's box room),
+ * parity unpinned by construction.  The pieces are the reference's and pinned on their own: the primary ray and the walk
+ * of trace3.cs (:805-807, :216-278; ids_*.npz fixtures), intersectRectangle / the LUT lookup / ltcEvaluate of trace2.cs
+ * (:189-194, :262-277, :163-184; analytic_trace2_*.npz fixtures).  Composition: the nearer of geometry and rectangle wins;
+ * a rectangle shows as (1,1,1) (:251-255); a geometry hit gets Kd * sum_i ltcEvaluate_i * f.x * intensity, plus Ke * 30
+ * when its material emits (trace3.cs:632); nothing hit: trace3's sky.  The colour is stored as is (trace2.cs:289-290). */
+void orc_trace_ltc(const orc_scene *scene, const orc_analytic_params *p, const float *rects, int32_t num_rects,
+                   float intensity, int32_t max_follows, float *color, int8_t *normal, uint16_t *pos, int32_t *tridx,
+                   int32_t *visits, int32_t *stats) {
+    const int W = p->width, H = p->height;
+    int x0 = p->x0, y0 = p->y0, x1 = p->x1, y1 = p->y1;
+    if (x0 == 0 && y0 == 0 && x1 == 0 && y1 == 0) { x1 = W; y1 = H; }
+    const v3 eye = ld3(p->eye), r00 = ld3(p->ray00), r01 = ld3(p->ray01), r10 = ld3(p->ray10), r11 = ld3(p->ray11);
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = y0; y < y1; y++) {
+        for (int x = x0; x < x1; x++) {
+            ctx_t c;
+            memset(&c, 0, sizeof c);
+            c.sc = scene;
+            c.px = x;
+            c.py = y;
+            c.max_follows = max_follows > 0 ? max_follows : 1000;
+            float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
+            v3 dir = normalize3(mix3(mix3(r00, r01, pyf), mix3(r10, r11, pyf), pxf));
+            SI_t SI;
+            intersectGeometry(&c, eye, dir, V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z), &SI);
+            const int found = SI.tridx != -1;
+            float smallest = found ? SI.t : 1E+10f; /* LARGE_FLOAT, trace2.cs:19 */
+            int rectHit = -1;
+            for (int i = 0; i < num_rects; i++) { /* trace2.cs:189-194 */
+                v3 rc = ld3(rects + 9 * i), rx = ld3(rects + 9 * i + 3), ry = ld3(rects + 9 * i + 6);
+                v3 n = cross3(rx, ry);
+                float den = dot3(n, dir), t = dot3(vsub(rc, eye), n) / den;
+                if (den != 0.0f && t > 0.0f && inrect(vadd(eye, vscale(dir, t)), rc, rx, ry) && t < smallest) {
+                    smallest = t;
+                    rectHit = i;
+                }
+            }
+            v3 L = V3(0.89f, 0.96f, 1.00f), nrm = V3(0, 0, 0), point = V3(0, 0, 0);
+            int id = -1;
+            if (rectHit >= 0) {
+                point = vadd(eye, vscale(dir, smallest));
+                nrm = cross3(ld3(rects + 9 * rectHit + 3), ld3(rects + 9 * rectHit + 6));
+                L = V3(1, 1, 1);
+                id = -2 - rectHit;
+            } else if (found) {
+                nrm = SI.normal;
+                point = SI.point;
+                id = SI.tridx;
+                const mtl_t *m = fetchMtl(&c, SI.matidx);
+                float uvx = p->roughness * 0.984375f + 0.0078125f;
+                float uvy = sqrtf(1.0f - fminf(1.0f, fmaxf(0.0f, dot3(nrm, vneg(dir))))) * 0.984375f + 0.0078125f;
+                v4 lm = ltcFetch(p->ltc1, uvx, uvy), lf = ltcFetch(p->ltc2, uvx, uvy);
+                float col = 0.0f;
+                for (int i = 0; i < num_rects; i++) {
+                    rect_t r = {ld3(rects + 9 * i), ld3(rects + 9 * i + 3), ld3(rects + 9 * i + 6)};
+                    col += ltcEvaluate(nrm, vneg(dir), point, lm, &r) * lf.x;
+                }
+                L = vscale(vscale(ld3(m->Kd), col), intensity);
+                if (m->emitter) L = vadd(L, vscale(ld3(m->Ke), 30.0f));
+            }
+            const size_t i = (size_t)y * W + x;
+            color[4 * i] = L.x; color[4 * i + 1] = L.y; color[4 * i + 2] = L.z; color[4 * i + 3] = 1.0f;
+            if (normal) {
+                normal[4 * i] = orc_f32_to_snorm8(nrm.x);
+                normal[4 * i + 1] = orc_f32_to_snorm8(nrm.y);
+                normal[4 * i + 2] = orc_f32_to_snorm8(nrm.z);
+                normal[4 * i + 3] = 0;
+            }
+            if (pos) {
+                pos[4 * i] = orc_f32_to_f16_rtz(point.x);
+                pos[4 * i + 1] = orc_f32_to_f16_rtz(point.y);
+                pos[4 * i + 2] = orc_f32_to_f16_rtz(point.z);
+                pos[4 * i + 3] = orc_f32_to_f16_rtz(1.0f);
+            }
+            if (tridx) tridx[i] = id;
+            if (visits) visits[i] = c.last_iterations;
+            if (stats) {
+                stats[4 * i] = c.rays; stats[4 * i + 1] = c.visits; stats[4 * i + 2] = c.tests; stats[4 * i + 3] = 0;
+            }
         }
     }
 }

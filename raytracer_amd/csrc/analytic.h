@@ -27,4 +27,9 @@ struct AnalyticTables { // rt_set_table contents; only the ones a kernel reads n
 hipError_t rtLaunchAnalytic(int kernel, const RtImages &img, const AnalyticParams &p, const AnalyticTables &tb,
                             const rt_rect &tile, RtCountersDev *counters, hipStream_t stream);
 
+// RT_KERNEL_TRACE3_LTC: `lights` = numRects x nine floats (c, x, y) in device memory
+hipError_t rtLaunchTrace3Ltc(const RtScene &sc, const RtImages &img, const AnalyticParams &p, const AnalyticTables &tb,
+                             const float *lights, int numRects, float intensity, int maxFollows, const rt_rect &tile,
+                             RtCountersDev *counters, hipStream_t stream);
+
 #endif

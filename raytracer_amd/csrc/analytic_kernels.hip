@@ -5,6 +5,7 @@
 //                                                    blue-noise sampler (Sobol / scramble / ranking byte tables)
 //   RT_KERNEL_TRACE2  reference src/shaders/trace2.cs  box room + 16 rectangle lights shaded with linearly
 //                                                    transformed cosines (two 64x64 RGBA32F look-up tables)
+//   RT_KERNEL_TRACE3_LTC  (no reference program)     trace2.cs's LTC shading at the primary hit of a BVH scene
 //
 // The scenes are compile-time constants (the shaders declare them `const`), so the intersection loops are
 // fully unrolled over literal operands: no scene memory traffic at all; these kernels are fp32-VALU bound.
@@ -446,7 +447,119 @@ __global__ __launch_bounds__(256) void rt_analytic_kernel(RtImages img, Analytic
     }
 }
 
+// RT_KERNEL_TRACE3_LTC — rectangle area lights shaded with linearly transformed cosines on a BVH scene.  NOT a program of
+// the reference (it has LTC shading only in trace2.cs's box room): the primary ray of trace3.cs (:805-807) walks the BVH
+// (traverse(): trace3.cs:216-278), the caller's rectangles are tested like trace2.cs's (intersectRectangle, :189-194; the
+// nearer of geometry and rectangle wins, a rectangle shows as vec3(1), :251-255), and a geometry hit is shaded as
+// trace2.cs:262-277 shades a box: the LUT pair looked up at (roughness, sqrt(1 - N.V)), the LTC integral of every rectangle
+// summed, times the hit material's Kd (the box colour's place) and the light intensity; an emitting material adds
+// Ke * 30 as trace3.cs:632 does at the first hit.  A ray that leaves the scene gets trace3's sky.  Deterministic: the
+// colour is stored as is (trace2.cs:289-290), the G-buffer as trace3's write() (:357-361).
+template <int NODES>
+__global__ __launch_bounds__(256) void rt_trace3_ltc_kernel(RtScene sc, RtImages img, AnalyticParams p, AnalyticTables tb,
+                                                            const Rect *__restrict__ rects, int numRects, float intensity,
+                                                            int maxFollows, rt_rect tile, int tilesX,
+                                                            RtCountersDev *counters) {
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lx = (lane & 7) + 8 * (wave & 1), ly = (lane >> 3) + 8 * (wave >> 1);
+    const int x = tile.x0 + (t % tilesX) * 16 + lx, y = tile.y0 + (t / tilesX) * 16 + ly;
+    const bool active = x < tile.x1 && y < tile.y1;
+    PathCtx c;
+    c.px = x;
+    c.py = y;
+    c.time = 0.0f;
+    c.seed = 0;
+    c.oob0 = c.oob1 = c.oob2 = 0.0f;
+    c.maxFollows = maxFollows > 0 ? maxFollows : 1000;
+    c.rays = c.visits = c.tests = c.shaded = 0;
+    c.lastIterations = 0;
+    c.blue = false;
+    c.frameIndex = c.drawn = 0;
+    c.tables = RtBlueTables{nullptr, nullptr, nullptr};
+    fillNodeCache(sc, sc.boxes);
+    if (active) {
+        const int W = img.width, H = img.height;
+        const size_t pix = (size_t)y * W + x;
+        const float pxf = ((float)x + 0.5f) / (float)W, pyf = ((float)y + 0.5f) / (float)H;
+        const f3 origin = ld3(p.eye);
+        const f3 dir = normalize(mix(mix(ld3(p.ray00), ld3(p.ray01), pyf), mix(ld3(p.ray10), ld3(p.ray11), pyf), pxf));
+        Hit h;
+        traverse<NODES, false>(sc, c, origin, dir, rcp3(dir), h);
+        const RtTri128 *tri = triPtr(sc, h.tridx);
+        float smallest = tri ? h.t : 1E+10f; // LARGE_FLOAT, trace2.cs:19
+        int rectHit = -1;
+        for (int i = 0; i < numRects; ++i) { // intersectRectangle, trace2.cs:189-194
+            const f3 rc = ld3(rects[i].c), rx = ld3(rects[i].x), ry = ld3(rects[i].y);
+            const f3 n = cross(rx, ry);
+            const float den = dot(n, dir), tr = dot(rc - origin, n) / den;
+            if (den != 0.0f && tr > 0.0f && inrect(origin + dir * tr, rc, rx, ry) && tr < smallest) {
+                smallest = tr;
+                rectHit = i;
+            }
+        }
+        f3 L = F3(0.89f, 0.96f, 1.00f), normal = F3(0, 0, 0), point = F3(0, 0, 0); // trace3's sky, zero G-buffer
+        int id = -1;
+        if (rectHit >= 0) {
+            point = origin + dir * smallest;
+            normal = cross(ld3(rects[rectHit].x), ld3(rects[rectHit].y)); // normalForRectangle, trace2.cs:234-236
+            L = F3(1, 1, 1);
+            id = -2 - rectHit;
+        } else if (tri) {
+            const float u = h.u, v = h.v, w = 1.0f - u - v;
+            normal = normalize((ld3(tri->n0) * w + ld3(tri->n1) * u) + ld3(tri->n2) * v); // trace3.cs:195-203
+            point = origin + dir * h.t;
+            id = h.tridx;
+            c.shaded++;
+            const RtMtl m = fetchMtl(sc, tri->mtlIndex);
+            // LUT_SCALE = 63/64, LUT_BIAS = 0.5/64 (trace2.cs:23-25), both exact in fp32
+            const float uvx = p.roughness * 0.984375f + 0.0078125f;
+            const float uvy = sqrtf(1.0f - fminf(1.0f, fmaxf(0.0f, dot(normal, -dir)))) * 0.984375f + 0.0078125f;
+            const float4 lm = ltcFetch(tb.ltc1, uvx, uvy), lf = ltcFetch(tb.ltc2, uvx, uvy);
+            float col = 0.0f;
+            for (int i = 0; i < numRects; ++i) col += ltcEvaluate(normal, -dir, point, lm, rects[i]) * lf.x;
+            L = (ld3(m.Kd) * col) * intensity;
+            if (m.emitter) L = L + ld3(m.Ke) * 30.0f;
+        }
+        img.color[pix] = make_float4(L.x, L.y, L.z, 1.0f);
+        img.normal[pix] = snorm8(normal.x) | (snorm8(normal.y) << 8) | (snorm8(normal.z) << 16);
+        img.pos[pix] = make_uint2(pack_half2_rtz(point.x, point.y), pack_half2_rtz(point.z, 1.0f));
+        if (p.flags & RT_FLAG_AUX) {
+            img.tridx[pix] = id; // triangle index; -2 - i = rectangle i; -1 = nothing
+            img.visits[pix] = c.lastIterations;
+        }
+        if (p.flags & RT_FLAG_PIXEL_STATS) img.stats[pix] = make_int4((int)c.rays, (int)c.visits, (int)c.tests, 0);
+    }
+    if (!(p.flags & RT_FLAG_NO_COUNTERS)) {
+        counters = counterShard(counters);
+        waveAdd(&counters->rays, c.rays);
+        waveAdd(&counters->node_visits, c.visits);
+        waveAdd(&counters->tri_tests, c.tests);
+        waveAdd(&counters->shaded_hits, c.shaded);
+        waveAdd(&counters->paths, active ? 1u : 0u);
+        waveAdd(&counters->primary_visits, c.visits);
+        waveAdd(&counters->primary_tests, c.tests);
+    }
+}
+
 } // namespace
+
+// lights: numRects records of nine floats (c, x, y: trace2.cs:41-45) in device memory
+hipError_t rtLaunchTrace3Ltc(const RtScene &sc, const RtImages &img, const AnalyticParams &p, const AnalyticTables &tb,
+                             const float *lights, int numRects, float intensity, int maxFollows, const rt_rect &tile,
+                             RtCountersDev *counters, hipStream_t stream) {
+    const int tw = tile.x1 - tile.x0, th = tile.y1 - tile.y0;
+    if (tw <= 0 || th <= 0) return hipSuccess;
+    const int tilesX = (tw + 15) / 16, tilesY = (th + 15) / 16;
+    RtScene cached = sc;
+    cached.cacheNodes = sc.packedLeaves ? (sc.numNodes < 896 ? sc.numNodes : 896) : 0;
+    const int nodes = rtNodeFetchFor(cached, cached.cacheNodes);
+    auto kernel = nodes == NODES_PLAIN ? rt_trace3_ltc_kernel<NODES_PLAIN>
+                  : nodes == NODES_PACKED_LDS ? rt_trace3_ltc_kernel<NODES_PACKED_LDS> : rt_trace3_ltc_kernel<NODES_PACKED>;
+    hipLaunchKernelGGL(kernel, dim3(tilesX * tilesY), dim3(256), (size_t)cached.cacheNodes * 32, stream, cached, img, p, tb,
+                       reinterpret_cast<const Rect *>(lights), numRects, intensity, maxFollows, tile, tilesX, counters);
+    return hipGetLastError();
+}
 
 hipError_t rtLaunchAnalytic(int kernel, const RtImages &img, const AnalyticParams &p, const AnalyticTables &tb,
                             const rt_rect &tile, RtCountersDev *counters, hipStream_t stream) {

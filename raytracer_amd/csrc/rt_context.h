@@ -35,6 +35,9 @@ struct rt_ctx {
 
     // scene
     DevBuf boxes, leaves, tris48, tris128, mtls, emitters, raw[11], tables[5];
+    DevBuf rectLights;                               // rt_set_rect_lights: nine floats per light (RT_KERNEL_TRACE3_LTC)
+    int numRectLights = 0;
+    float rectIntensity = 6.0f;                      // LIGHT_INTENSITY, trace2.cs:20
     DevBuf cells;         // slots 7 + 8 as the Q-table kernel's cell search reads them (RtQTable::cells)
     bool cellsStale = true;
     DevBuf spec;          // decision-tree table of the row-mode walk (RtScene::spec); hasSpec says whether it is valid

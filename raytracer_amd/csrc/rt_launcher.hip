@@ -386,6 +386,7 @@ void rt_destroy(rt_ctx *c) {
     for (DevBuf &b : c->raw) releaseBuf(b);
     releaseBuf(c->cells);
     for (DevBuf &b : c->tables) releaseBuf(b);
+    releaseBuf(c->rectLights);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -578,6 +579,25 @@ int rt_set_table(rt_ctx *c, int table, const void *bytes, size_t nbytes) {
     if (r) return r;
     if ((r = rtJoinLanes(c))) return r;
     return uploadTo(c, c->tables[table], bytes, nbytes);
+}
+
+int rt_set_rect_lights(rt_ctx *c, const rt_rect_light *lights, int n, float intensity) {
+    if (!c) return RT_EINVAL;
+    if (n < 0 || n > RT_MAX_RECT_LIGHTS || (n > 0 && !lights)) return fail(c, RT_EINVAL, "rt_set_rect_lights: 0..64 lights");
+    static_assert(sizeof(rt_rect_light) == 36, "nine floats per light");
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(lights[i].c[k]) || !std::isfinite(lights[i].x[k]) || !std::isfinite(lights[i].y[k]))
+                return fail(c, RT_EINVAL, "rt_set_rect_lights: light " + std::to_string(i) + " is not finite");
+    if (!std::isfinite(intensity)) return fail(c, RT_EINVAL, "rt_set_rect_lights: intensity is not finite");
+    int r = bind(c);
+    if (r) return r;
+    if ((r = rtJoinLanes(c))) return r;
+    c->numRectLights = 0;
+    if (n > 0 && (r = uploadTo(c, c->rectLights, lights, (size_t)n * sizeof(rt_rect_light)))) return r;
+    c->numRectLights = n;
+    c->rectIntensity = intensity;
+    return RT_OK;
 }
 
 int rt_clear(rt_ctx *c) {
@@ -1037,6 +1057,44 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             span.end();
             if (e != hipSuccess) return hipFail(c, e, "trace3 RL launch");
         }
+        return RT_OK;
+    }
+    case RT_KERNEL_TRACE3_LTC: {
+        if ((rc = rtJoinLanes(c))) return rc;
+        c->flatValid = false;
+        // trace2.cs's LTC shading at the primary hit of the uploaded BVH scene (analytic_kernels.hip); deterministic, so a
+        // batch of n is one launch
+        if (!c->boxes.p || !c->tris48.p || !c->mtls.p)
+            return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
+        if (c->maxTriEnd > c->numTris)
+            return fail(c, RT_ECORRUPT, "rt_trace: a leaf references triangles beyond the uploaded triangle stream");
+        if (!c->tables[RT_TABLE_LTC1].p || !c->tables[RT_TABLE_LTC2].p)
+            return fail(c, RT_ESTATE, "rt_trace: RT_KERNEL_TRACE3_LTC needs the ltc1 and ltc2 tables (rt_set_table)");
+        if (p->flags & (RT_FLAG_WATERTIGHT | RT_FLAG_FAST_SHADOWS | RT_FLAG_WEIGHTED_LIGHTS | RT_FLAG_BLUE_NOISE))
+            return fail(c, RT_EINVAL, "rt_trace: RT_KERNEL_TRACE3_LTC takes RT_FLAG_AUX, RT_FLAG_PIXEL_STATS and RT_FLAG_NO_COUNTERS only");
+        RtScene sc;
+        RtImages img;
+        fillScene(c, sc, img);
+        AnalyticParams ap;
+        std::memset(&ap, 0, sizeof ap);
+        std::memcpy(ap.eye, p->eye, sizeof ap.eye);
+        std::memcpy(ap.ray00, p->ray00, sizeof ap.ray00);
+        std::memcpy(ap.ray01, p->ray01, sizeof ap.ray01);
+        std::memcpy(ap.ray10, p->ray10, sizeof ap.ray10);
+        std::memcpy(ap.ray11, p->ray11, sizeof ap.ray11);
+        ap.roughness = p->roughness;
+        ap.flags = p->flags;
+        ap.batch = 1;
+        AnalyticTables tb;
+        tb.sobol = tb.scramble = tb.ranking = nullptr;
+        tb.ltc1 = (const float4 *)c->tables[RT_TABLE_LTC1].p;
+        tb.ltc2 = (const float4 *)c->tables[RT_TABLE_LTC2].p;
+        SpanGuard span(c, TK_TRACE), span2(c, RT_TIME_PER_PIXEL);
+        hipError_t e = rtLaunchTrace3Ltc(sc, img, ap, tb, (const float *)c->rectLights.p, c->numRectLights, c->rectIntensity,
+                                         p->maxFollows, r, (RtCountersDev *)c->counters.p, c->stream);
+        span2.end();
+        span.end();
+        if (e != hipSuccess) return hipFail(c, e, "LTC kernel launch");
         return RT_OK;
     }
     case RT_KERNEL_TRACE: case RT_KERNEL_TRACE1: case RT_KERNEL_TRACE2: {

@@ -12,7 +12,8 @@ LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(_HERE, "lib", "librt_hip
 (IMAGE_COLOR, IMAGE_NORMAL, IMAGE_POSITION, IMAGE_FILTERED, IMAGE_TRIDX, IMAGE_VISITS, IMAGE_STATS,
  IMAGE_LDR, IMAGE_ASSEMBLED) = range(9)
 COMM_ID_BYTES = 128
-KERNEL_TRACE3, KERNEL_TRACE3_RL, KERNEL_TRACE, KERNEL_TRACE1, KERNEL_TRACE2 = range(5)
+KERNEL_TRACE3, KERNEL_TRACE3_RL, KERNEL_TRACE, KERNEL_TRACE1, KERNEL_TRACE2, KERNEL_TRACE3_LTC = range(6)
+MAX_RECT_LIGHTS = 64
 FLAG_AUX, FLAG_PIXEL_STATS, FLAG_NO_COUNTERS, FLAG_PER_PIXEL_KERNEL, FLAG_FAST_SHADOWS, FLAG_WATERTIGHT = 1, 2, 4, 8, 16, 32
 FLAG_WEIGHTED_LIGHTS = 64
 FLAG_BLUE_NOISE = 128
@@ -77,7 +78,7 @@ class ScheduleInfo(ctypes.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_[1:]}
 
 
-EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_upload", "rt_set_table", "rt_download", "rt_resize",
+EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_upload", "rt_set_table", "rt_set_rect_lights", "rt_download", "rt_resize",
            "rt_clear", "rt_trace", "rt_trace_batch", "rt_trace_batch_static", "rt_static_max_paths", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
            "rt_readback_rect_device", "rt_write_rect_device", "rt_write_rect_device_async", "rt_write_image", "rt_image_pixel_bytes",
            "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
@@ -104,6 +105,7 @@ def lib():
         L.rt_set_stream.argtypes = [vp, vp]
         L.rt_upload.argtypes = [vp, i32, vp, sz]
         L.rt_set_table.argtypes = [vp, i32, vp, sz]
+        L.rt_set_rect_lights.argtypes = [vp, vp, i32, ctypes.c_float]
         L.rt_download.argtypes = [vp, i32, vp, sz]
         L.rt_resize.argtypes = [vp, i32, i32]
         L.rt_clear.argtypes = [vp]
@@ -224,6 +226,13 @@ class Context:
     def set_table(self, table, data):
         data = bytes(data)
         self._check(lib().rt_set_table(self._h, table, data, len(data)), f"rt_set_table({table})")
+
+    def set_rect_lights(self, lights, intensity=6.0):
+        """lights: (n, 3, 3) float32 — corner c, edge vectors x, y per light (reference trace2.cs:41-45 `rectangle`) for
+        KERNEL_TRACE3_LTC; an empty array removes them."""
+        a = np.ascontiguousarray(np.asarray(lights, dtype=np.float32).reshape(-1, 9))
+        self._check(lib().rt_set_rect_lights(self._h, a.ctypes.data if len(a) else None, len(a), float(intensity)),
+                    "rt_set_rect_lights")
 
     def resize(self, width, height):
         self._check(lib().rt_resize(self._h, width, height), "rt_resize")
