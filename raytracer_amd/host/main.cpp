@@ -1,11 +1,14 @@
 // main.cpp — headless counterpart of the reference's window loop (reference src/main.cpp:6-138):
 // same objects built in the same order, `frames` iterations of trace (+ filter), then PNGs.
 //   rt_headless scene.obj [--size WxH] [--frames N] [--bounces B] [--filter ITERS] [--exposure E]
-//               [--auto-camera] [--light] [--out PREFIX] [--res DIR] [--kernel trace3|trace|trace1|trace2]
+//               [--auto-camera] [--light] [--out PREFIX] [--res DIR] [--kernel trace3|trace|trace1|trace2|trace3ltc]
+//               [--rect-light cx,cy,cz,xx,xy,xz,yx,yy,yz]... [--light-intensity I] [--roughness R]   (trace3ltc)
 //               [--keys "FRAME:KEY,FRAME:KEY,..."] [--reset-at FRAME] [--freeze-time] [--dump-raw PREFIX] [--gpus N]
 //               [--watertight] [--fast-shadows] [--weighted-lights] [--blue-noise]   (opt-in variants, include/rt_launcher.h)
 // --kernel selects one of the reference's other kernels (its analytic box scenes; the obj file is still loaded,
 // as the reference's main does, but not traced); trace1 / trace2 read their tables from --res (default "res").
+// --kernel trace3ltc is not a program of the reference: trace2.cs's LTC shading at the primary hit of the obj scene, lit by
+// the --rect-light rectangles (corner, edge x, edge y; RT_KERNEL_TRACE3_LTC in include/rt_launcher.h).
 // --keys feeds the reference's input handler (glfw_setter.hpp) before the given frame of the loop: W A S D Z X move the
 // camera and restart the accumulation, COMMA / PERIOD change maxBounces (restart), SPACE toggles the filter, MINUS /
 // EQUAL change its iterations, 1 / 2 the exposure, SCROLL+n / SCROLL-n the field of view, MOUSE<x>x<y> moves the cursor
@@ -45,6 +48,8 @@ struct Options {
     std::string out = "frame", res = "res", kernel = "trace3", dumpRaw;
     int launchFlags = 0, maxFollows = 1000, resetAt = -1;
     std::vector<std::pair<int, std::string>> keys; // (frame, key name)
+    std::vector<rt_rect_light> rectLights;          // --rect-light (kernel trace3ltc)
+    float lightIntensity = 6.0f, roughness = 0.5f;  // LIGHT_INTENSITY of trace2.cs:20; the `roughness` uniform
 };
 
 struct FrameState { // what the loop of reference main.cpp:67-134 sees at the top of one iteration
@@ -161,7 +166,9 @@ void renderOn(Shared &sh, int rank, int nranks) {
                                      std::vector<const char *>{main_cs.c_str(), "src/shaders/random.glsl"});
         tracer.resourceDir = o.res;
         if (o.kernel == "trace1" || (o.launchFlags & RT_FLAG_BLUE_NOISE)) tracer.genBlueNoiseBuffers();
-        if (o.kernel == "trace2") tracer.genLtcData();
+        if (o.kernel == "trace2" || o.kernel == "trace3ltc") tracer.genLtcData();
+        if (o.kernel == "trace3ltc") tracer.setRectLights(o.rectLights, o.lightIntensity);
+        tracer.roughness = o.roughness;
         tracer.launchFlags = o.launchFlags;
         tracer.maxFollows = o.maxFollows;
         rtCheck(api.profile(ctx, 1), "rt_profile");
@@ -273,6 +280,16 @@ int main(int argc, char **argv) {
         else if (a == "--out") o.out = next();
         else if (a == "--res") o.res = next();
         else if (a == "--kernel") o.kernel = next();
+        else if (a == "--rect-light") {
+            rt_rect_light l;
+            if (std::sscanf(next(), "%f,%f,%f,%f,%f,%f,%f,%f,%f", &l.c[0], &l.c[1], &l.c[2], &l.x[0], &l.x[1], &l.x[2], &l.y[0],
+                            &l.y[1], &l.y[2]) != 9) {
+                std::cerr << "--rect-light wants nine comma-separated numbers (corner, edge x, edge y)" << std::endl;
+                return -1;
+            }
+            o.rectLights.push_back(l);
+        } else if (a == "--light-intensity") o.lightIntensity = (float)std::atof(next());
+        else if (a == "--roughness") o.roughness = (float)std::atof(next());
         else if (a == "--watertight") o.launchFlags |= RT_FLAG_WATERTIGHT;      // opt-in variants, not the reference's algorithm
         else if (a == "--fast-shadows") o.launchFlags |= RT_FLAG_FAST_SHADOWS;
         else if (a == "--weighted-lights") o.launchFlags |= RT_FLAG_WEIGHTED_LIGHTS;
@@ -293,7 +310,7 @@ int main(int argc, char **argv) {
             }
         } else { std::cerr << "unknown option " << a << std::endl; return -1; }
     }
-    if (o.kernel != "trace3" && o.kernel != "trace" && o.kernel != "trace1" && o.kernel != "trace2") {
+    if (o.kernel != "trace3" && o.kernel != "trace" && o.kernel != "trace1" && o.kernel != "trace2" && o.kernel != "trace3ltc") {
         std::cerr << "unknown kernel " << o.kernel << std::endl;
         return -1;
     }

@@ -28,7 +28,8 @@ ComputeShader::ComputeShader(std::vector<const char *> shaderPathVector) {
     ID = RT_KERNEL_TRACE3;
     if (!shaderPathVector.empty() && shaderPathVector[0]) {
         const std::string p(shaderPathVector[0]);
-        if (p.find("trace3") != std::string::npos) ID = RT_KERNEL_TRACE3;
+        if (p.find("trace3ltc") != std::string::npos) ID = RT_KERNEL_TRACE3_LTC; // (no file of the reference: rt_launcher.h)
+        else if (p.find("trace3") != std::string::npos) ID = RT_KERNEL_TRACE3;
         else if (p.find("trace1") != std::string::npos) ID = RT_KERNEL_TRACE1;
         else if (p.find("trace2") != std::string::npos) ID = RT_KERNEL_TRACE2;
         else if (p.find("trace") != std::string::npos) ID = RT_KERNEL_TRACE;
@@ -168,6 +169,11 @@ void Tracer::genLtcData() { // Tracer.cpp:23-48
         rtCheck(rtApi().set_table(rtCurrentContext(), RT_TABLE_LTC1, b.data(), b.size()), "rt_set_table(ltc1)");
     if (readWhole(resourceDir + "/ltc2.data", b))
         rtCheck(rtApi().set_table(rtCurrentContext(), RT_TABLE_LTC2, b.data(), b.size()), "rt_set_table(ltc2)");
+}
+
+// Not in the reference (its trace2.cs holds the rectangles as shader constants, :47-64): the lights of RT_KERNEL_TRACE3_LTC
+void Tracer::setRectLights(const std::vector<rt_rect_light> &lights, float intensity) {
+    rtCheck(rtApi().set_rect_lights(rtCurrentContext(), lights.data(), (int)lights.size(), intensity), "rt_set_rect_lights");
 }
 
 void Tracer::genBlueNoiseBuffers() { // Tracer.cpp:50-90

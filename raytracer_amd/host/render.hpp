@@ -123,6 +123,8 @@ public:
     rt_rect tile = {0, 0, 0, 0};
     std::string resourceDir = "res"; // where the sample tables / LUTs are read from
     rt_counters counters();
+    // Not in the reference: the rectangle lights of RT_KERNEL_TRACE3_LTC (a Tracer built from "trace3ltc.cs")
+    void setRectLights(const std::vector<rt_rect_light> &lights, float intensity = 6.0f);
 
 private:
     float lastTime = 0.0f; // the `time` of the last dispatch (what freezeTime freezes)

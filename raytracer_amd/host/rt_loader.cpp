@@ -53,6 +53,7 @@ const RtApi &rtApi() {
     bindSym(lib, "rt_set_stream", g_api.set_stream);
     bindSym(lib, "rt_upload", g_api.upload);
     bindSym(lib, "rt_set_table", g_api.set_table);
+    bindSym(lib, "rt_set_rect_lights", g_api.set_rect_lights);
     bindSym(lib, "rt_resize", g_api.resize);
     bindSym(lib, "rt_clear", g_api.clear);
     bindSym(lib, "rt_trace", g_api.trace);

@@ -15,6 +15,7 @@ struct RtApi {
     int (*set_stream)(rt_ctx *, void *);
     int (*upload)(rt_ctx *, int, const void *, size_t);
     int (*set_table)(rt_ctx *, int, const void *, size_t);
+    int (*set_rect_lights)(rt_ctx *, const rt_rect_light *, int, float);
     int (*resize)(rt_ctx *, int, int);
     int (*clear)(rt_ctx *);
     int (*trace)(rt_ctx *, const rt_trace_params *, const rt_rect *);

@@ -194,3 +194,25 @@ def test_headless_blue_noise_flag(tmp_path):
     ref = orclib.trace(orclib.Scene(wl.buffers), W, H, wl.rays, wl.eye, spp=3, max_bounces=4,
                        blue_noise={k: tables[k] for k in ("sobol", "scramble", "ranking")})
     check_against_oracle(got, ref, 0, "headless blue noise")
+
+
+def test_headless_ltc_rectangle_lights_on_the_obj_scene(tmp_path):
+    """rt_headless --kernel trace3ltc (RT_KERNEL_TRACE3_LTC, not a program of the reference): the C++ mirror's path — a
+    Tracer built from "trace3ltc.cs", genLtcData from --res, Tracer::setRectLights, the `roughness` uniform — against the
+    CPU oracle's same mode, with two filter passes on top."""
+    from oracle import orclib
+    from tests.test_gpu_ltc_bvh import room_lights
+    W, H = 128, 72
+    res = os.path.dirname(assets.path("ltc1.data"))
+    assets.path("ltc2.data")
+    lights = room_lights()
+    args = []
+    for l in lights.reshape(-1, 9):
+        args += ["--rect-light", ",".join(repr(float(v)) for v in l)]
+    prefix, _ = run_headless(tmp_path, "room.obj", "--size", f"{W}x{H}", "--frames", 2, "--filter", 2, "--kernel", "trace3ltc",
+                             "--res", res, "--roughness", 0.25, "--light-intensity", 5.0, *args)
+    got = load_dump(prefix, W, H, True)
+    wl = workloads.Workload("room", W, H)
+    ref = orclib.trace_ltc(orclib.Scene(wl.buffers), W, H, wl.rays, wl.eye, lights, workloads.analytic_tables(),
+                           roughness=0.25, intensity=5.0)
+    check_against_oracle(got, ref, 2, "headless trace3ltc")
