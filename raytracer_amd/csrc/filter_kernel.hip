@@ -129,8 +129,9 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
                                                         const uint2 *__restrict__ colorF16,
                                                         const uint32_t *__restrict__ normal,
                                                         const uint2 *__restrict__ pos, uint2 *__restrict__ out, int W,
-                                                        int H, rt_rect rect, int tilesX, float c_phi, float n_phi,
-                                                        float p_phi, int step, RtFilterCells cells) {
+                                                        int H, rt_rect rect, int tilesX, int tilesY, int locality,
+                                                        float c_phi, float n_phi, float p_phi, int step,
+                                                        RtFilterCells cells) {
     static_assert(TX * TY == 256, "one pixel per thread");
     static_assert((TX / 16 + 1) * ((TY + 14) / 16 + 1) <= 256, "one thread per cell a tile can touch");
     extern __shared__ __align__(16) unsigned char lds[];
@@ -143,8 +144,28 @@ __global__ __launch_bounds__(256) void rt_atrous_kernel(const float4 *__restrict
     // Consecutive blocks go to consecutive XCDs.  With as many tiles per row as XCDs (256-pixel tiles, 1920 pixels) a
     // plain row-major order would hand one XCD every tile of a column — all of the image's left edge, say, none of
     // which can use the flat-cell results while most tiles of other columns can: the columns are rotated row by row.
-    const int tileRow = (int)blockIdx.x / tilesX;
-    const int tileCol = ((int)blockIdx.x % tilesX + tileRow) % tilesX;
+    // That order is for frames with flat cells (locality == 0).  Without them every tile costs the same and what counts
+    // is that the texels two tiles share are fetched into ONE XCD's L2 once: each XCD then takes a contiguous part of the
+    // image (block b runs on XCD b % 8): an eighth of the tiles, numbered column by column for the 256 x 1 tiles, whose
+    // taps reach up to 63 rows up and down (with 1920 pixels: one tile column per XCD), row by row for the others (a
+    // band of the image).
+    int tileRow, tileCol;
+    if (!locality) {
+        if ((int)blockIdx.x >= tilesX * tilesY) return; // (the grid is padded for the other order)
+        tileRow = (int)blockIdx.x / tilesX;
+        tileCol = ((int)blockIdx.x % tilesX + tileRow) % tilesX;
+    } else {
+        const int perXcd = (tilesX * tilesY + 7) >> 3;
+        const int t = ((int)blockIdx.x & 7) * perXcd + ((int)blockIdx.x >> 3);
+        if (t >= tilesX * tilesY) return;
+        if (BANDS) {
+            tileCol = t / tilesY;
+            tileRow = t - tileCol * tilesY;
+        } else {
+            tileRow = t / tilesX;
+            tileCol = t - tileRow * tilesX;
+        }
+    }
     const int x0 = rect.x0 + tileCol * TX, y0 = rect.y0 + tileRow * TY;
     const PassScalars ks = passScalars(c_phi, n_phi, p_phi, step);
     // Flat cells (rt_device.h): a tile all of whose cells have this pass's result per cell stores those and is done.
@@ -280,7 +301,8 @@ __device__ __forceinline__ bool sameTexel(const RtFlatCells &rec, int a, int b) 
 }
 
 __global__ __launch_bounds__(256) void rt_flat_levels_kernel(RtFlatCells rec, uint8_t *__restrict__ level,
-                                                             uint2 *__restrict__ texels, int W, int H, FlatPasses pp) {
+                                                             uint2 *__restrict__ texels, int *__restrict__ patchFlat, int W,
+                                                             int H, FlatPasses pp) {
     constexpr int SIDE = 16 + 2 * FL_MAXR;
     __shared__ uint8_t sGood[SIDE * SIDE];
     const int patchesX = (rec.cellsX + 15) / 16;
@@ -318,11 +340,11 @@ __global__ __launch_bounds__(256) void rt_flat_levels_kernel(RtFlatCells rec, ui
     __syncthreads();
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int cx = pcx + lx, cy = pcy + ly;
-    if (cx >= rec.cellsX || cy >= rec.cellsY) return;
+    const bool inGrid = cx < rec.cellsX && cy < rec.cellsY;
     const int cell = cy * rec.cellsX + cx;
     const int px = cx << RT_CELL_SHIFT, py = cy << RT_CELL_SHIFT;
     int lvl = 0, reach = 0;
-    for (int i = 0; i < pp.passes; ++i) {
+    for (int i = 0; inGrid && i < pp.passes; ++i) {
         reach += (2 << i) - 1;
         if (px - reach < 0 || py - reach < 0 || px + 15 + reach >= W || py + 15 + reach >= H) break;
         const int R = (reach + 15) >> RT_CELL_SHIFT;
@@ -332,6 +354,10 @@ __global__ __launch_bounds__(256) void rt_flat_levels_kernel(RtFlatCells rec, ui
         if (!all) break;
         lvl = i + 1;
     }
+    // how many cells of this patch have a result at all: a later rt_filter picks the passes' block order by the sum
+    const int flatHere = __syncthreads_count(lvl > 0);
+    if (threadIdx.x == 0) patchFlat[blockIdx.x] = flatHere;
+    if (!inGrid) return;
     level[cell] = (uint8_t)lvl;
     if (lvl == 0) return;
     float4 c, nv, pv;
@@ -376,8 +402,10 @@ __global__ __launch_bounds__(256) void rt_tonemap_kernel(const float4 *__restric
 
 int rtAtrousMaxStep() { return FT_MAXSTEP; }
 
-// level: one byte per cell; texels: RT_FLAT_MAX_PASSES planes of one uint2 per cell; phis: c_phi, n_phi, p_phi per pass
-hipError_t rtLaunchFlatLevels(const RtFlatCells &rec, uint8_t *level, uint2 *texels, int W, int H, int passes,
+// level: one byte per cell; texels: RT_FLAT_MAX_PASSES planes of one uint2 per cell; patchFlat: one int per 16 x 16 patch of
+// cells (rtFlatPatches); phis: c_phi, n_phi, p_phi per pass
+int rtFlatPatches(int cellsX, int cellsY) { return ((cellsX + 15) / 16) * ((cellsY + 15) / 16); }
+hipError_t rtLaunchFlatLevels(const RtFlatCells &rec, uint8_t *level, uint2 *texels, int *patchFlat, int W, int H, int passes,
                               const float *c_phi, const float *n_phi, const float *p_phi, hipStream_t stream) {
     if (passes < 1 || passes > RT_FLAT_MAX_PASSES) return hipErrorInvalidValue;
     FlatPasses pp;
@@ -388,21 +416,23 @@ hipError_t rtLaunchFlatLevels(const RtFlatCells &rec, uint8_t *level, uint2 *tex
         pp.p_phi[i] = i < passes ? p_phi[i] : 1.0f;
     }
     const int patches = ((rec.cellsX + 15) / 16) * ((rec.cellsY + 15) / 16);
-    hipLaunchKernelGGL(rt_flat_levels_kernel, dim3(patches), dim3(256), 0, stream, rec, level, texels, W, H, pp);
+    hipLaunchKernelGGL(rt_flat_levels_kernel, dim3(patches), dim3(256), 0, stream, rec, level, texels, patchFlat, W, H, pp);
     return hipGetLastError();
 }
 
 hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const uint32_t *normal, const uint2 *pos,
                           uint2 *out, int W, int H, const rt_rect &rect, float c_phi, float n_phi, float p_phi,
-                          int step, const RtFilterCells &cells, hipStream_t stream) {
+                          int step, const RtFilterCells &cells, int locality, hipStream_t stream) {
     const int rw = rect.x1 - rect.x0, rh = rect.y1 - rect.y0;
     if (rw <= 0 || rh <= 0) return hipSuccess;
     // tile shape by step width: the fewest staged texels per output pixel (48 bytes of LDS each)
     auto launch = [&](auto kernel, int TX, int TY, bool bands) {
         const int tilesX = (rw + TX - 1) / TX, tilesY = (rh + TY - 1) / TY;
         const size_t ldsBytes = (size_t)(bands ? 3 * TY : TY + 2 * step) * (TX + 2 * step) * 48;
-        hipLaunchKernelGGL(kernel, dim3(tilesX * tilesY), dim3(256), ldsBytes, stream, colorF32, colorF16, normal, pos,
-                           out, W, H, rect, tilesX, c_phi, n_phi, p_phi, step, cells);
+        int blocks = tilesX * tilesY;
+        if (locality) blocks = 8 * ((blocks + 7) / 8); // (the order of rt_atrous_kernel: up to 7 blocks of the padded grid have no tile)
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), ldsBytes, stream, colorF32, colorF16, normal, pos,
+                           out, W, H, rect, tilesX, tilesY, locality, c_phi, n_phi, p_phi, step, cells);
     };
     if (step <= 2) launch(rt_atrous_kernel<16, 16, false>, 16, 16, false);
     else if (step <= 4) launch(rt_atrous_kernel<32, 8, false>, 32, 8, false);

@@ -27,6 +27,7 @@ struct TimedSpan {
     bool stopShared = false; // the next span on the stream starts at this one's stop event (and returns it to the pool)
 };
 
+#define RT_MAX_FLAT_PATCHES 1024 // 16 x 16 patches of 16 x 16-pixel cells: images up to 8192 x 8192 pixels (larger ones keep the flat-cell order)
 struct rt_ctx {
     int device = 0;
     hipStream_t ownStream = nullptr;
@@ -57,7 +58,7 @@ struct rt_ctx {
     // per-cell results of its passes).  flatValid: the record describes colour, normals and positions as they are
     // now inside flatRect (the tile of the frame that made it) — cleared by every other writer of those images.
     // useFlatCells: RT_FILTER_CELLS=0 turns the shortcut off (the images are the same either way; tests compare the two).
-    DevBuf flatFlag, flatColor, flatNormal, flatPos, flatLevel, flatTexels;
+    DevBuf flatFlag, flatColor, flatNormal, flatPos, flatLevel, flatTexels, flatPatch;
     bool flatValid = false, useFlatCells = true;
     bool filterUsedFlat = false; // the last rt_filter ran with the record (flatLevel then belongs to the filtered image)
     rt_rect flatRect = {0, 0, 0, 0};
@@ -97,6 +98,9 @@ struct rt_ctx {
     // rays a stage of the frame it is launching will hold, but frames of one scene resemble each other, so the sizes of
     // the last frame choose each stage's extend kernel (row mode for sparse stages).  Never changes the picture.
     int *hostCounts = nullptr;          // pinned, 32 ints
+    // Flat cells per 16 x 16 patch of cells as an earlier rt_filter counted them (pinned; -1: nothing known): the block order
+    // of the filter passes follows their sum (rt_filter).  Never changes the picture.
+    int *hostFlatPatch = nullptr;       // pinned, RT_MAX_FLAT_PATCHES ints
     hipEvent_t countsEvent = nullptr;
     bool countsPending = false, havePrediction = false;
     int predictedCounts[32] = {};
@@ -112,6 +116,7 @@ struct rt_ctx {
     int tuneRaysPerWave = 0, tuneCoop = -1, tuneFill = 0, tuneChunk = 64;          // RT_WF_RAYS_PER_WAVE, RT_WF_COOP
     int tunePairs = -1;                              // RT_WF_PAIRS (WfParams::extendPairs)
     int tuneLongWalk = 0;                            // RT_WF_LONG_WALK (WfParams::longWalk)
+    int tuneFilterMap = -1;                          // RT_FILTER_MAP: block order of the filter passes (-1: by the flat-cell record, 0 / 1: rt_atrous_kernel)
     int tuneRowStaticK = 8, tuneRowChunkDiv = 2;     // RT_WF_ROW_STATIC, RT_WF_ROW_CHUNK_DIV (WfParams::rowStaticK / rowChunkDiv)
     int tuneRowMode = -1, tuneRowMaxRays = -1;       // RT_WF_ROWS (0 never, 1 always, 2 per stage by ray count), RT_WF_ROW_MAX_RAYS
     int tuneCacheNodes = 896;                        // RT_WF_CACHE_NODES: 28 KB + 12 KB of wave scratch per block, 4 blocks per CU

@@ -25,11 +25,12 @@ struct rt_ctx;
 void rtMarkKernel(void *ctxOpaque, int kind, bool begin);
 hipError_t rtLaunchAtrous(const float4 *colorF32, const uint2 *colorF16, const uint32_t *normal, const uint2 *pos,
                           uint2 *out, int W, int H, const rt_rect &rect, float c_phi, float n_phi, float p_phi,
-                          int step, const RtFilterCells &cells, hipStream_t stream);
+                          int step, const RtFilterCells &cells, int locality, hipStream_t stream);
 hipError_t rtLaunchTonemap(const float4 *colorF32, const uint2 *colorF16, uint32_t *out, int W, const rt_rect &rect,
                            float exposure, hipStream_t stream);
-hipError_t rtLaunchFlatLevels(const RtFlatCells &rec, uint8_t *level, uint2 *texels, int W, int H, int passes,
+hipError_t rtLaunchFlatLevels(const RtFlatCells &rec, uint8_t *level, uint2 *texels, int *patchFlat, int W, int H, int passes,
                               const float *c_phi, const float *n_phi, const float *p_phi, hipStream_t stream);
+int rtFlatPatches(int cellsX, int cellsY);
 int rtAtrousMaxStep();
 hipError_t rtLaunchBuildPairs(const float4 *boxesP, const int2 *leaves, int numNodes, const float4 *tris48, float4 *pairs,
                               int *slotTri, int numSlots, hipStream_t stream); // wavefront.hip
@@ -320,12 +321,15 @@ int rt_create(int device_id, rt_ctx **out) {
         rtStaticScratchPtr[device_id] = ptr;
     }
     if (hipHostMalloc((void **)&c->hostCounts, 32 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void **)&c->hostFlatPatch, RT_MAX_FLAT_PATCHES * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&c->countsEvent, hipEventDisableTiming) != hipSuccess) {
         (void)hipStreamDestroy(c->ownStream);
         delete c;
         return RT_ENOMEM;
     }
+    for (int i = 0; i < RT_MAX_FLAT_PATCHES; ++i) c->hostFlatPatch[i] = -1;
     if (const char *e = std::getenv("RT_FILTER_CELLS")) c->useFlatCells = std::atoi(e) != 0;
+    if (const char *e = std::getenv("RT_FILTER_MAP")) c->tuneFilterMap = std::max(-1, std::min(1, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_REFILL")) c->tuneRefillLanes = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_CACHE_NODES")) c->tuneCacheNodes = std::max(0, std::min(3800, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_RAYS_PER_WAVE")) c->tuneRaysPerWave = std::max(0, std::min(64, std::atoi(e)));
@@ -363,6 +367,7 @@ void rt_destroy(rt_ctx *c) {
     rtCommRelease(c);
     if (c->countsEvent) (void)hipEventDestroy(c->countsEvent);
     if (c->hostCounts) (void)hipHostFree(c->hostCounts);
+    if (c->hostFlatPatch) (void)hipHostFree(c->hostFlatPatch);
     for (TimedSpan &s : c->spans) {
         (void)hipEventDestroy(s.start);
         (void)hipEventDestroy(s.stop);
@@ -372,7 +377,7 @@ void rt_destroy(rt_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     DevBuf *all[] = {&c->boxes, &c->leaves, &c->tris48, &c->tris128, &c->mtls, &c->emitters, &c->color, &c->normal,
                      &c->pos, &c->filt[0], &c->filt[1], &c->tridx, &c->visits, &c->stats, &c->ldr, &c->counters,
-                     &c->spec, &c->triPairs, &c->boxesP, &c->slotTri, &c->flatFlag, &c->flatColor, &c->flatNormal, &c->flatPos, &c->flatLevel, &c->flatTexels};
+                     &c->spec, &c->triPairs, &c->boxesP, &c->slotTri, &c->flatFlag, &c->flatColor, &c->flatNormal, &c->flatPos, &c->flatLevel, &c->flatTexels, &c->flatPatch};
     for (rt_ctx::Lane &L : c->lane) {
         for (DevBuf &b : L.wfState) releaseBuf(b);
         for (DevBuf &b : L.wfRay) releaseBuf(b);
@@ -634,6 +639,7 @@ int rt_resize(rt_ctx *c, int width, int height) {
         L.dirty = false;
     }
     rtCommQuiesce(c);
+    for (int i = 0; i < RT_MAX_FLAT_PATCHES; ++i) c->hostFlatPatch[i] = -1; // (every stream is idle: no copy in flight) nothing known about the new images
     if (width != c->width || height != c->height) c->assembledPixelBytes = 0; // the assembled frame belongs to the old size
     const size_t n = (size_t)width * height;
     if ((r = ensure(c, c->color, n * 16)) || (r = ensure(c, c->normal, n * 4)) || (r = ensure(c, c->pos, n * 8)) ||
@@ -643,7 +649,7 @@ int rt_resize(rt_ctx *c, int width, int height) {
     const size_t cellCount = (size_t)((width + 15) >> RT_CELL_SHIFT) * (size_t)((height + 15) >> RT_CELL_SHIFT);
     if ((r = ensure(c, c->flatFlag, cellCount)) || (r = ensure(c, c->flatColor, cellCount * 16)) ||
         (r = ensure(c, c->flatNormal, cellCount * 4)) || (r = ensure(c, c->flatPos, cellCount * 8)) ||
-        (r = ensure(c, c->flatLevel, cellCount)) || (r = ensure(c, c->flatTexels, cellCount * 8 * RT_FLAT_MAX_PASSES)))
+        (r = ensure(c, c->flatLevel, cellCount)) || (r = ensure(c, c->flatPatch, 4 * (size_t)rtFlatPatches((width + 15) >> RT_CELL_SHIFT, (height + 15) >> RT_CELL_SHIFT))) || (r = ensure(c, c->flatTexels, cellCount * 8 * RT_FLAT_MAX_PASSES)))
         return r;
     c->walkTune.state = 0;
     c->walkTune.pending = false;
@@ -1275,12 +1281,31 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
         rec.cellsX = cellsX;
         rec.cellsY = cellsY;
         SpanGuard span(c, TK_FILTER);
-        hipError_t e = rtLaunchFlatLevels(rec, (uint8_t *)c->flatLevel.p, (uint2 *)c->flatTexels.p, c->width, c->height,
+        hipError_t e = rtLaunchFlatLevels(rec, (uint8_t *)c->flatLevel.p, (uint2 *)c->flatTexels.p, (int *)c->flatPatch.p, c->width, c->height,
                                           iterations, cp, np, pp, c->stream);
         span.end();
         if (e != hipSuccess) return hipFail(c, e, "flat levels launch");
     }
     c->filterUsedFlat = flat;
+    // Block order of the passes (filter_kernel.hip: rt_atrous_kernel).  With many flat cells the order that spreads the
+    // tiles which cannot use them over the XCDs; otherwise the order that gives each XCD one contiguous part of the image,
+    // so that the texels neighbouring tiles share are fetched from HBM once (measured on room.obj: 2.3 x the compulsory
+    // bytes -> 1.0-1.1 x).  How many cells are flat is known on the device only: the count the levels kernel made for an
+    // EARLIER call (copied to pinned memory behind that call's last pass, never waited for) decides; until one has
+    // arrived the flat-cell order is used.  Either order gives the same image.
+    const int patches = rtFlatPatches(cellsX, cellsY);
+    int locality = flat ? 0 : 1;
+    if (flat && patches <= RT_MAX_FLAT_PATCHES) {
+        long long flatCells = 0;
+        bool known = true;
+        for (int i = 0; i < patches; ++i) {
+            const int v = c->hostFlatPatch[i];
+            if (v < 0) known = false;
+            flatCells += v;
+        }
+        if (known && 4 * flatCells < (long long)cellsX * cellsY) locality = 1;
+    }
+    if (c->tuneFilterMap >= 0) locality = c->tuneFilterMap;
     for (int i = 0; i < iterations; ++i) {
         const float c_phi = 1.0f / (float)i * c_phi0; // +inf at i = 0, as the reference computes it
         const float p_phi = 1.0f / (float)(1 << i) * p_phi0;
@@ -1304,7 +1329,7 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
         SpanGuard span(c, TK_FILTER);
         hipError_t e = rtLaunchAtrous(readF32, readF16, (const uint32_t *)c->normal.p, (const uint2 *)c->pos.p,
                                       (uint2 *)c->filt[write].p, c->width, c->height, r, c_phi, n_phi, p_phi, step,
-                                      cells, c->stream);
+                                      cells, locality, c->stream);
         span.end();
         if (e != hipSuccess) return hipFail(c, e, "atrous launch");
         readF32 = nullptr;
@@ -1312,6 +1337,8 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
         c->filteredIndex = write;
         write ^= 1;
     }
+    if (flat && patches <= RT_MAX_FLAT_PATCHES) // for a later call's choice of block order (above)
+        HIP_TRY(c, hipMemcpyAsync(c->hostFlatPatch, c->flatPatch.p, (size_t)patches * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     return RT_OK;
 }
 
