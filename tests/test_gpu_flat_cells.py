@@ -166,3 +166,46 @@ def test_the_record_is_dropped_when_something_else_writes_the_images():
     finally:
         on.close()
         off.close()
+
+
+def _ctx_with_env(wl, W, H, **env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        ctx = hiplib.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    ctx.upload_scene(wl.buffers)
+    ctx.resize(W, H)
+    return ctx
+
+
+@pytest.mark.parametrize("scene,W,H", [("room", 333, 187), ("room", 1920, 1080), ("scene", 640, 360)])
+def test_block_order_of_the_passes_does_not_change_the_image(scene, W, H):
+    """The filter passes run in one of two block orders (filter_kernel.hip: the flat-cell order, or one contiguous part of
+    the image per XCD), picked by the launcher from the flat-cell count an earlier call read back.  RT_FILTER_MAP pins
+    the order: both, and the launcher's own choice over several calls (the order changes between them once the count
+    has arrived), must give the same bytes - full frame, every number of passes, and a tile with its halo."""
+    wl = workloads.Workload(scene, W, H)
+    ctxs = [_ctx_with_env(wl, W, H, RT_FILTER_MAP=0), _ctx_with_env(wl, W, H, RT_FILTER_MAP=1), make_ctx(wl, W, H, True)]
+    try:
+        for c in ctxs:
+            c.trace_samples(wl.rays, wl.eye, spp=2, max_bounces=3, num_emitters=wl.num_emitters)
+        tile = (W // 5, H // 4, W // 5 + 97, H // 4 + 61)
+        for it in (1, 2, 3, 5, 5, 5):  # (repeated: the third context's choice follows the read-back of its earlier calls)
+            outs = []
+            for c in ctxs:
+                c.filter(it)
+                outs.append(c.readback(hiplib.IMAGE_FILTERED).view(np.uint16).copy())
+                c.filter(it, rect=tile)
+                outs.append(c.readback(hiplib.IMAGE_FILTERED).view(np.uint16)[tile[1]:tile[3], tile[0]:tile[2]].copy())
+            for k in (2, 4):
+                assert np.array_equal(outs[0], outs[k]), (scene, it, k)
+                assert np.array_equal(outs[1], outs[k + 1]), (scene, it, k, "tile")
+    finally:
+        for c in ctxs:
+            c.close()
