@@ -612,6 +612,12 @@ def main():
     ms_per_step = elapsed * 1e3 / a.steps
     mrays = frame_rays * a.steps / elapsed / 1e6
     rl = with_alone(roofline(K, tm, cnt, wl, W, H, a.spp, a.filter, a.steps, scene_key, stop_at_root or 0), alone)
+    if rl is not None and world == 1:
+        # the whole timed region against the same roof: every traversal's algorithmic operations / the driver-timed interval
+        ops = 25.0 * float(cnt.node_visits) + 51.0 * float(cnt.tri_tests)
+        rl["timed_region"] = {"algorithmic_ops_per_frame": round(ops / a.steps), "achieved_Tops": round(ops / elapsed / 1e12, 4),
+                              "frac_of_valu_peak": round(ops / elapsed / 1e12 / VALU_PEAK_TOPS_NOFMA, 4),
+                              "note": "all kernels of the frame, frames in flight included: trace + filter time, traversal operations only"}
     frame_name = f"{scene_key}{'.obj' if not lattice else ''} {W}x{H} {a.spp}spp"
     headline = (a.scene, W, H, a.spp, a.bounces, a.filter) == ("scene", 1920, 1080, 4, 5, 5)
     out = {
