@@ -35,7 +35,7 @@ struct rt_ctx {
     std::string error;
 
     // scene
-    DevBuf boxes, leaves, tris48, tris128, mtls, emitters, raw[11], tables[5];
+    DevBuf boxes, leaves, tris36, tris128, mtls, emitters, raw[11], tables[5];
     DevBuf rectLights;                               // rt_set_rect_lights: nine floats per light (RT_KERNEL_TRACE3_LTC)
     int numRectLights = 0;
     float rectIntensity = 6.0f;                      // LIGHT_INTENSITY, trace2.cs:20

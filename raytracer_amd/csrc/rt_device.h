@@ -8,7 +8,10 @@
 //           32-byte read gives the box, both links and the leaf range;
 //           plain form (anything else): w0 = hitNext, w1 = missNext, leaf range from `leaves`
 //   leaves  int2[N]       node i → {firstTri, numTris}                                    8 B
-//   tris48  float4[3*T]   triangle j → {v0,0}, {v1-v0,0}, {v2-v0,0}                      48 B, 16-B aligned
+//   tris36  float[9*T]    triangle j → v0, v1-v0, v2-v0                                    36 B, no padding (4-B aligned:
+//           read with two 16-byte loads and one 4-byte load, loadTri36 below; round 2 kept 48-byte records of three
+//           float4 — the vector-memory data path of a CU returns 16 dwords per clock and a dwordx3 load occupies it like a
+//           dwordx4, so a test cost 48 of its clocks against 36 now, and on room.obj that path is 94 % busy: DESIGN.md 4.2)
 //   triPairs float4[5*S/2] packed scenes: the same values leaf by leaf, two triangles per 80-B record, interleaved
 //           component by component for packed fp32 arithmetic (RtScene::triPairs); a packed leaf word's range is in
 //           SLOTS of this stream (every leaf starts at an even slot), slotTri[slot] = triangle index
@@ -55,7 +58,7 @@ static_assert(sizeof(RtNode48) == 48, "node record");
 struct RtScene {
     const float4 *boxes;
     const int2 *leaves;
-    const float4 *tris48;
+    const float *tris36;
     const RtTri128 *tris128;
     const RtMtl *mtls;
     const RtTri128 *emitters;

@@ -32,7 +32,7 @@ hipError_t rtLaunchFlatLevels(const RtFlatCells &rec, uint8_t *level, uint2 *tex
                               const float *c_phi, const float *n_phi, const float *p_phi, hipStream_t stream);
 int rtFlatPatches(int cellsX, int cellsY);
 int rtAtrousMaxStep();
-hipError_t rtLaunchBuildPairs(const float4 *boxesP, const int2 *leaves, int numNodes, const float4 *tris48, float4 *pairs,
+hipError_t rtLaunchBuildPairs(const float4 *boxesP, const int2 *leaves, int numNodes, const float *tris36, float4 *pairs,
                               int *slotTri, int numSlots, hipStream_t stream); // wavefront.hip
 // rt_comm.hip
 void rtCommQuiesce(rt_ctx *c);
@@ -201,12 +201,12 @@ static int rebuildPairs(rt_ctx *c) {
         c->pairsValid = true;
         return RT_OK;
     }
-    if (!c->packedLeaves || !c->boxesP.p || !c->tris48.p || c->maxTriEnd > c->numTris) return RT_OK;
+    if (!c->packedLeaves || !c->boxesP.p || !c->tris36.p || c->maxTriEnd > c->numTris) return RT_OK;
     int r;
     if ((r = ensure(c, c->triPairs, (size_t)(c->numSlots / 2) * 80)) || (r = ensure(c, c->slotTri, (size_t)c->numSlots * 4)))
         return r;
     hipError_t e = rtLaunchBuildPairs((const float4 *)c->boxesP.p, (const int2 *)c->leaves.p, c->numNodes,
-                                      (const float4 *)c->tris48.p, (float4 *)c->triPairs.p, (int *)c->slotTri.p,
+                                      (const float *)c->tris36.p, (float4 *)c->triPairs.p, (int *)c->slotTri.p,
                                       c->numSlots, c->stream);
     if (e != hipSuccess) return hipFail(c, e, "pair stream build");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -252,7 +252,7 @@ static int lanesInUse(const rt_ctx *c) {
     int lanes = std::min(c->framesInFlight, c->lanesAvailable);
     // (a scene beyond the L2s is bound by HBM: a fourth frame in flight only adds to the cache misses — config #5
     // 20.5 ms per frame with three, 21.3 ms with four — unless the caller asked for it)
-    const size_t hot = c->boxes.bytes + c->leaves.bytes + c->tris48.bytes;
+    const size_t hot = c->boxes.bytes + c->leaves.bytes + c->tris36.bytes;
     if (!c->lanesByCaller && hot > (size_t)3 * 1024 * 1024) lanes = std::min(lanes, 3);
     return lanes;
 }
@@ -375,7 +375,7 @@ void rt_destroy(rt_ctx *c) {
     for (hipEvent_t e : c->eventPool) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->walkTune.ev)
         if (e) (void)hipEventDestroy(e);
-    DevBuf *all[] = {&c->boxes, &c->leaves, &c->tris48, &c->tris128, &c->mtls, &c->emitters, &c->color, &c->normal,
+    DevBuf *all[] = {&c->boxes, &c->leaves, &c->tris36, &c->tris128, &c->mtls, &c->emitters, &c->color, &c->normal,
                      &c->pos, &c->filt[0], &c->filt[1], &c->tridx, &c->visits, &c->stats, &c->ldr, &c->counters,
                      &c->spec, &c->triPairs, &c->boxesP, &c->slotTri, &c->flatFlag, &c->flatColor, &c->flatNormal, &c->flatPos, &c->flatLevel, &c->flatTexels, &c->flatPatch};
     for (rt_ctx::Lane &L : c->lane) {
@@ -528,15 +528,17 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
         const size_t n = nbytes / sizeof(RtTri128);
         if (n > 0x7FFFFFFFu / 3) return fail(c, RT_EINVAL, "rt_upload: triangle count out of range");
         const RtTri128 *src = static_cast<const RtTri128 *>(bytes);
-        std::vector<float4> t48(3 * n);
+        std::vector<float> t36(9 * n);
         for (size_t i = 0; i < n; ++i) {
             const RtTri128 &s = src[i];
             // e1 = v1 - v0, e2 = v2 - v0: the first two operations of geometry.glsl:32, done once
-            t48[3 * i] = make_float4(s.v0[0], s.v0[1], s.v0[2], 0.0f);
-            t48[3 * i + 1] = make_float4(s.v1[0] - s.v0[0], s.v1[1] - s.v0[1], s.v1[2] - s.v0[2], 0.0f);
-            t48[3 * i + 2] = make_float4(s.v2[0] - s.v0[0], s.v2[1] - s.v0[1], s.v2[2] - s.v0[2], 0.0f);
+            for (int k = 0; k < 3; ++k) {
+                t36[9 * i + k] = s.v0[k];
+                t36[9 * i + 3 + k] = s.v1[k] - s.v0[k];
+                t36[9 * i + 6 + k] = s.v2[k] - s.v0[k];
+            }
         }
-        if ((r = uploadTo(c, c->tris48, t48.data(), t48.size() * sizeof(float4)))) return r;
+        if ((r = uploadTo(c, c->tris36, t36.data(), t36.size() * sizeof(float)))) return r;
         if ((r = uploadTo(c, c->tris128, bytes, nbytes))) return r;
         c->numTris = (int)n;
         c->pairsValid = false;
@@ -665,7 +667,7 @@ namespace {
 void fillScene(const rt_ctx *c, RtScene &sc, RtImages &img) {
     sc.boxes = (const float4 *)c->boxes.p;
     sc.leaves = (const int2 *)c->leaves.p;
-    sc.tris48 = (const float4 *)c->tris48.p;
+    sc.tris36 = (const float *)c->tris36.p;
     sc.tris128 = (const RtTri128 *)c->tris128.p;
     sc.mtls = (const RtMtl *)c->mtls.p;
     sc.emitters = (const RtTri128 *)c->emitters.p;
@@ -758,7 +760,7 @@ namespace {
 int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rect &r, const RtScene &sc,
                    const RtImages &img, WfBuffers &wf, bool noAlloc, hipEvent_t beforeCommit = nullptr) {
     const rt_trace_params *p = &params[0];
-    const size_t hot = c->boxes.bytes + c->leaves.bytes + c->tris48.bytes;
+    const size_t hot = c->boxes.bytes + c->leaves.bytes + c->tris36.bytes;
     const int xcdRemap = hot > (size_t)3 * 1024 * 1024;
     const size_t tilePixels = (size_t)(r.x1 - r.x0) * (size_t)(r.y1 - r.y0);
     wf.tilePixels = (int)tilePixels;
@@ -932,7 +934,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     if (rc) return rc;
     switch (p->kernel) {
     case RT_KERNEL_TRACE3: {
-        if (!c->boxes.p || !c->tris48.p || !c->mtls.p)
+        if (!c->boxes.p || !c->tris36.p || !c->mtls.p)
             return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
         if (c->maxTriEnd > c->numTris)
             return fail(c, RT_ECORRUPT, "rt_trace: a leaf references triangles beyond the uploaded triangle stream");
@@ -940,7 +942,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         RtImages img;
         fillScene(c, sc, img);
         // scene bytes the traversal touches vs. one XCD's 4 MiB L2
-        const size_t hot = c->boxes.bytes + c->leaves.bytes + c->tris48.bytes;
+        const size_t hot = c->boxes.bytes + c->leaves.bytes + c->tris36.bytes;
         const int xcdRemap = hot > (size_t)3 * 1024 * 1024;
         const size_t tilePixels = (size_t)(r.x1 - r.x0) * (size_t)(r.y1 - r.y0);
         if (tilePixels == 0) return RT_OK;
@@ -1024,7 +1026,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         if ((rc = rtJoinLanes(c))) return rc;
         c->flatValid = false;
         // traceRL (reference trace3.cs:695-791): the scene of trace3 plus the Q-table state of slots 7..10.
-        if (!c->boxes.p || !c->tris48.p || !c->mtls.p)
+        if (!c->boxes.p || !c->tris36.p || !c->mtls.p)
             return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
         if (c->maxTriEnd > c->numTris)
             return fail(c, RT_ECORRUPT, "rt_trace: a leaf references triangles beyond the uploaded triangle stream");
@@ -1070,7 +1072,7 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
         c->flatValid = false;
         // trace2.cs's LTC shading at the primary hit of the uploaded BVH scene (analytic_kernels.hip); deterministic, so a
         // batch of n is one launch
-        if (!c->boxes.p || !c->tris48.p || !c->mtls.p)
+        if (!c->boxes.p || !c->tris36.p || !c->mtls.p)
             return fail(c, RT_ESTATE, "rt_trace: nodes, triangles and materials must be uploaded first");
         if (c->maxTriEnd > c->numTris)
             return fail(c, RT_ECORRUPT, "rt_trace: a leaf references triangles beyond the uploaded triangle stream");
@@ -1182,7 +1184,7 @@ int rt_trace_batch_static(rt_ctx *c, const rt_trace_params *params, int n, const
     if ((p->flags & RT_FLAG_BLUE_NOISE) &&
         (!c->tables[RT_TABLE_SOBOL].p || !c->tables[RT_TABLE_SCRAMBLE].p || !c->tables[RT_TABLE_RANKING].p))
         return fail(c, RT_ESTATE, "rt_trace_batch_static: RT_FLAG_BLUE_NOISE needs the sobol, scramble and ranking tables (rt_set_table)");
-    if (!c->boxes.p || !c->tris48.p || !c->mtls.p)
+    if (!c->boxes.p || !c->tris36.p || !c->mtls.p)
         return fail(c, RT_ESTATE, "rt_trace_batch_static: nodes, triangles and materials must be uploaded first");
     if (c->maxTriEnd > c->numTris)
         return fail(c, RT_ECORRUPT, "rt_trace_batch_static: a leaf references triangles beyond the uploaded triangle stream");

@@ -196,6 +196,17 @@ __device__ __forceinline__ float randomTriangleAreaDirectionPDF(f3 p, const Ligh
 }
 
 // ---------------------------------------------------------------- leaf test
+// One 36-byte triangle record {v0, e1, e2} (rt_device.h: tris36) as three float4 (w = 0): two 16-byte loads and one
+// 4-byte load at 4-byte alignment, which gfx950's global loads accept.
+typedef float rt_f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void loadTri36(const float *__restrict__ tris36, int i, float4 &a0, float4 &a1, float4 &a2) {
+    const float *p = tris36 + 9 * (size_t)i;
+    const rt_f4u lo = *reinterpret_cast<const rt_f4u *>(p), hi = *reinterpret_cast<const rt_f4u *>(p + 4);
+    const float last = p[8];
+    a0 = make_float4(lo.x, lo.y, lo.z, 0.0f);
+    a1 = make_float4(lo.w, hi.x, hi.y, 0.0f);
+    a2 = make_float4(hi.z, hi.w, last, 0.0f);
+}
 // intersectTriangle (geometry.glsl:31-51) on one {v0, e1, e2} record; e1, e2 were subtracted at upload
 // with the same fp32 operations.  Updates the closest hit with the strict `<` of trace3.cs:177.
 // EARLY_OUT = true leaves at the first failed condition, as the reference does: right for coherent waves (primary
@@ -255,15 +266,16 @@ __device__ __forceinline__ bool triangleCandidate(const float4 a0, const float4 
 // order, four records (12 aligned 16-byte loads) are requested before the first of them is tested so
 // that the load latency of a leaf is paid once per four triangles instead of once per triangle.
 template <bool EARLY_OUT>
-__device__ __forceinline__ void testLeaf(const float4 *__restrict__ tris48, int first, int end, f3 origin, f3 dir,
+__device__ __forceinline__ void testLeaf(const float *__restrict__ tris36, int first, int end, f3 origin, f3 dir,
                                          float &nearest, int &hitTri, float &hitT, float &hitU, float &hitV) {
     for (int i = first; i < end; i += 4) {
         const int last = end - 1;
         const int i1 = min(i + 1, last), i2 = min(i + 2, last), i3 = min(i + 3, last);
-        const float4 a0 = tris48[3 * i], a1 = tris48[3 * i + 1], a2 = tris48[3 * i + 2];
-        const float4 b0 = tris48[3 * i1], b1 = tris48[3 * i1 + 1], b2 = tris48[3 * i1 + 2];
-        const float4 c0 = tris48[3 * i2], c1 = tris48[3 * i2 + 1], c2 = tris48[3 * i2 + 2];
-        const float4 d0 = tris48[3 * i3], d1 = tris48[3 * i3 + 1], d2 = tris48[3 * i3 + 2];
+        float4 a0, a1, a2, b0, b1, b2, c0, c1, c2, d0, d1, d2;
+        loadTri36(tris36, i, a0, a1, a2);
+        loadTri36(tris36, i1, b0, b1, b2);
+        loadTri36(tris36, i2, c0, c1, c2);
+        loadTri36(tris36, i3, d0, d1, d2);
         testTriangle<EARLY_OUT>(a0, a1, a2, i, origin, dir, nearest, hitTri, hitT, hitU, hitV);
         if (i + 1 < end) testTriangle<EARLY_OUT>(b0, b1, b2, i + 1, origin, dir, nearest, hitTri, hitT, hitU, hitV);
         if (i + 2 < end) testTriangle<EARLY_OUT>(c0, c1, c2, i + 2, origin, dir, nearest, hitTri, hitT, hitU, hitV);
@@ -640,7 +652,7 @@ __device__ __forceinline__ bool traverse(const RtScene &sc, PathCtx &c, f3 origi
         if (WATERTIGHT)
             testLeafWt(sc.tris128, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
         else
-            testLeaf<true>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
+            testLeaf<true>(sc.tris36, leafFirst, leafFirst + leafCount, origin, dir, nearest, hit.tridx, hit.t, hit.u, hit.v);
         tests += (unsigned)leafCount;
     }
     c.lastIterations = iterations;

@@ -711,8 +711,14 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                     }
                 } else {
                     // (RT_FLAG_WATERTIGHT: v0..v2 are the three vertices from the 128-byte records instead of {v0, e1, e2})
-                    const float4 *triData = WATERTIGHT ? reinterpret_cast<const float4 *>(sc.tris128) : sc.tris48;
-                    constexpr int triStride = WATERTIGHT ? 8 : 3;
+                    auto loadEntry = [&](int tri, float4 &v0, float4 &v1, float4 &v2) {
+                        if constexpr (WATERTIGHT) {
+                            const float4 *t128 = reinterpret_cast<const float4 *>(sc.tris128);
+                            v0 = t128[8 * tri], v1 = t128[8 * tri + 1], v2 = t128[8 * tri + 2];
+                        } else {
+                            loadTri36(sc.tris36, tri, v0, v1, v2);
+                        }
+                    };
                     struct Pair { // entry g of the list: ray of rank o, triangle tri
                         int g, o, tri;
                         float4 v0, v1, v2;
@@ -724,9 +730,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                     if (pa.g < totalTests) {
                         pa.o = rankBase + __popcll(heads & atOrBelow);
                         pa.tri = ws->first[pa.o] + pa.g;
-                        pa.v0 = triData[triStride * pa.tri];
-                        pa.v1 = triData[triStride * pa.tri + 1];
-                        pa.v2 = triData[triStride * pa.tri + 2];
+                        loadEntry(pa.tri, pa.v0, pa.v1, pa.v2);
                     }
                     auto round = [&](const Pair &cur, Pair &nxt, int base) {
                         nxt.g = cur.g + 64;
@@ -735,9 +739,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                         if (nxt.g < totalTests) {
                             nxt.o = rankBase + __popcll(heads & atOrBelow);
                             nxt.tri = ws->first[nxt.o] + nxt.g;
-                            nxt.v0 = triData[triStride * nxt.tri];
-                            nxt.v1 = triData[triStride * nxt.tri + 1];
-                            nxt.v2 = triData[triStride * nxt.tri + 2];
+                            loadEntry(nxt.tri, nxt.v0, nxt.v1, nxt.v2);
                         }
                         if (cur.g < totalTests) {
                             const float4 ro = ws->ro[cur.o], rd = ws->rd[cur.o];
@@ -782,8 +784,9 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                             testTriangleWt(xyz(triData[8 * won]), xyz(triData[8 * won + 1]), xyz(triData[8 * won + 2]), won,
                                            origin, wtSetup(dir), nearest, hitTri, hitT, hitU, hitV);
                         } else {
-                            testTriangle<false>(sc.tris48[3 * won], sc.tris48[3 * won + 1], sc.tris48[3 * won + 2], won, origin, dir,
-                                                nearest, hitTri, hitT, hitU, hitV);
+                            float4 w0, w1, w2;
+                            loadTri36(sc.tris36, won, w0, w1, w2);
+                            testTriangle<false>(w0, w1, w2, won, origin, dir, nearest, hitTri, hitT, hitU, hitV);
                         }
                     }
                     tests += (unsigned)leafCount;
@@ -800,7 +803,7 @@ __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams 
                 else if constexpr (PAIRS)
                     testLeafPairs(sc.triPairs, leafFirst, leafCount, makeRayP(origin, dir), nearest, hitTri, hitT, hitU, hitV);
                 else
-                    testLeaf<false>(sc.tris48, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
+                    testLeaf<false>(sc.tris36, leafFirst, leafFirst + leafCount, origin, dir, nearest, hitTri, hitT, hitU, hitV);
                 tests += (unsigned)leafCount;
             }
             if (bounded && hitTri >= 0) next = -1; // any hit nearer than the light settles a shadow ray
@@ -1047,16 +1050,8 @@ __global__ __launch_bounds__(1024) void rt_wf_extend_rows_kernel(RtScene sc, WfP
             const int i0 = leafFirst + rowLane, i1 = i0 + 16;
             const bool has0 = rowLane < leafCount, has1 = rowLane + 16 < leafCount;
             float4 a0 = make_float4(0, 0, 0, 0), a1 = a0, a2 = a0, d0 = a0, d1 = a0, d2 = a0;
-            if (has0) {
-                a0 = sc.tris48[3 * i0];
-                a1 = sc.tris48[3 * i0 + 1];
-                a2 = sc.tris48[3 * i0 + 2];
-            }
-            if (has1) {
-                d0 = sc.tris48[3 * i1];
-                d1 = sc.tris48[3 * i1 + 1];
-                d2 = sc.tris48[3 * i1 + 2];
-            }
+            if (has0) loadTri36(sc.tris36, i0, a0, a1, a2);
+            if (has1) loadTri36(sc.tris36, i1, d0, d1, d2);
             WT(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const long long cl = clock64(); wtLoad += cl - c2;)
             unsigned bestKey = 0xFFFFFFFFu;
             float bestT = 0.0f, bestU = 0.0f, bestV = 0.0f;
@@ -1214,7 +1209,7 @@ __global__ __launch_bounds__(256) void rt_wf_blend_kernel(RtImages img, WfParams
 // One thread per node: a leaf's {v0, e1, e2} records, two triangles per 80-byte record, interleaved component by
 // component (trace3_device.h: testPair), written at the slots its record in boxesP names; slotTri maps back.
 __global__ __launch_bounds__(256) void rt_build_pairs_kernel(const float4 *__restrict__ boxes, const int2 *__restrict__ leaves,
-                                                             int numNodes, const float4 *__restrict__ tris48,
+                                                             int numNodes, const float *__restrict__ tris36,
                                                              float4 *__restrict__ pairs, int *__restrict__ slotTri,
                                                              int numSlots) {
     const int node = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1227,8 +1222,9 @@ __global__ __launch_bounds__(256) void rt_build_pairs_kernel(const float4 *__res
         const int ia = lr.x + k;
         const bool hasB = k + 1 < lr.y;
         const float4 z = make_float4(0, 0, 0, 0);
-        const float4 a0 = tris48[3 * ia], a1 = tris48[3 * ia + 1], a2 = tris48[3 * ia + 2];
-        const float4 b0 = hasB ? tris48[3 * ia + 3] : z, b1 = hasB ? tris48[3 * ia + 4] : z, b2 = hasB ? tris48[3 * ia + 5] : z;
+        float4 a0, a1, a2, b0 = z, b1 = z, b2 = z;
+        loadTri36(tris36, ia, a0, a1, a2);
+        if (hasB) loadTri36(tris36, ia + 1, b0, b1, b2);
         float4 *out = pairs + (size_t)5 * ((s0 + k) >> 1);
         out[0] = make_float4(a0.x, b0.x, a0.y, b0.y);
         out[1] = make_float4(a0.z, b0.z, a1.x, b1.x);
@@ -1240,10 +1236,10 @@ __global__ __launch_bounds__(256) void rt_build_pairs_kernel(const float4 *__res
     }
 }
 
-hipError_t rtLaunchBuildPairs(const float4 *boxesP, const int2 *leaves, int numNodes, const float4 *tris48, float4 *pairs,
+hipError_t rtLaunchBuildPairs(const float4 *boxesP, const int2 *leaves, int numNodes, const float *tris36, float4 *pairs,
                               int *slotTri, int numSlots, hipStream_t stream) {
     if (numNodes <= 0 || numSlots <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rt_build_pairs_kernel, dim3((numNodes + 255) / 256), dim3(256), 0, stream, boxesP, leaves, numNodes, tris48,
+    hipLaunchKernelGGL(rt_build_pairs_kernel, dim3((numNodes + 255) / 256), dim3(256), 0, stream, boxesP, leaves, numNodes, tris36,
                        pairs, slotTri, numSlots);
     return hipGetLastError();
 }
