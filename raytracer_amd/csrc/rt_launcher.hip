@@ -197,6 +197,10 @@ void rtMarkKernel(void *opaque, int kind, bool begin) {
 // gets none; such a scene is refused at launch anyway (RT_ECORRUPT).
 static int rebuildPairs(rt_ctx *c) {
     c->pairsValid = false;
+    // Opt-in (RT_WF_PAIRS=1) since the triangle records are 36 bytes: the pair record's one advantage was bytes per
+    // triangle (40 against 48), and it now has none (config #5 with pairs / without: 18.39 / 18.39 ms per frame, one
+    // frame on its own 21.98 / 21.35 ms), while it costs 40 bytes per triangle of memory and a second set of node records.
+    if (c->tunePairs <= 0) return RT_OK;
     if (c->packedLeaves && c->boxesP.p && c->numSlots <= 0) { // a tree without leaves: nothing to pair, nothing is ever read
         c->pairsValid = true;
         return RT_OK;
@@ -514,7 +518,8 @@ int rt_upload(rt_ctx *c, int slot, const void *bytes, size_t nbytes) {
             c->hasSpec = true;
         }
         if ((r = uploadTo(c, c->boxes, boxes.data(), boxes.size() * sizeof(float4)))) return r;
-        if (packed && (r = uploadTo(c, c->boxesP, boxesP.data(), boxesP.size() * sizeof(float4)))) return r;
+        // (the pair stream and its node records are kept only when the pair tests are asked for: RT_WF_PAIRS=1, below)
+        if (packed && c->tunePairs > 0 && (r = uploadTo(c, c->boxesP, boxesP.data(), boxesP.size() * sizeof(float4)))) return r;
         if ((r = uploadTo(c, c->leaves, leaves.data(), leaves.size() * sizeof(int2)))) return r;
         c->numNodes = (int)n;
         c->maxTriEnd = (int)maxEnd;

@@ -31,7 +31,7 @@ struct WfParams {
     int walkMin;           // ... if at least walkMin lanes are walking
     int extendChunk;       // most queue entries a wave takes with one atomic on the shared cursor
     int extendCoop;        // leaf tests of full waves: 0 lane by lane, 1 cooperative, 2 decided per round (see coopA / coopB)
-    int extendPairs;       // leaves two triangles at a time from the pair stream: 1 always, 0 never, -1 for scenes beyond the L2s
+    int extendPairs;       // leaves two triangles at a time from the pair stream: 1 on (RT_WF_PAIRS=1), otherwise off
     int coopA, coopB;      // a round is tested cooperatively when rounds_of_64_pairs * coopA + coopB < 4 * largest_leaf
     WfSample s[WF_MAX_BATCH];
 };

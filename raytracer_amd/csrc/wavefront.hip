@@ -400,8 +400,9 @@ struct WaveShare { // phase-2 exchange area of one wave (3 KB); first/ro/rd/key 
 // PAIRS: leaves are tested two triangles at a time on packed fp32 from the pair stream (trace3_device.h: testPair).
 // Measured on MI355X (scripts/micro/pk_rate.hip): a v_pk_mul_f32 / v_pk_add_f32 occupies the issue slot
 // 1.7 times as long as its scalar form, so the packed test buys at most 1.19x in arithmetic throughput and lengthens
-// every dependent chain; room.obj did not change, the metric frame lost 10 %.  What it does buy is bytes (40 per
-// triangle instead of 48), so the launcher uses it for scenes beyond the L2s (config #5: -7.5 %) and nowhere else.
+// every dependent chain; room.obj did not change, the metric frame lost 10 %.  What it did buy was bytes (40 per
+// triangle instead of the 48 of round 2's records: config #5 -7.5 %); with the 36-byte records it buys nothing any more
+// (config #5 18.39 ms either way), so it is an opt-in variant (RT_WF_PAIRS=1) kept under test, not a default.
 template <int NODES, bool WATERTIGHT, bool PAIRS>
 __global__ __launch_bounds__(256) void rt_wf_extend_kernel(RtScene sc, WfParams p, WfBuffers wf, int stage,
                                                            int refillLanes, RtCountersDev *counters) {
@@ -1283,7 +1284,7 @@ hipError_t rtLaunchWavefront(const RtScene &sc, const RtImages &imgOut, const Wf
     // the walk's node fetch is chosen here, once per launch (trace3_device.h: loadNodeT)
     const int extendNodes = !sc.packedLeaves ? NODES_PLAIN : scExtend.cacheNodes >= sc.numNodes ? NODES_PACKED_LDS : NODES_PACKED;
     // two triangles per test on packed fp32 (the pair stream): only where its smaller records pay, beyond the L2s
-    const bool pairs = extendNodes != NODES_PLAIN && !wt && sc.boxesP && (p.extendPairs > 0 || (p.extendPairs < 0 && xcdRemap));
+    const bool pairs = extendNodes != NODES_PLAIN && !wt && sc.boxesP && p.extendPairs > 0;
     auto extendKernel = extendNodes == NODES_PLAIN ? (wt ? rt_wf_extend_kernel<NODES_PLAIN, true, false> : rt_wf_extend_kernel<NODES_PLAIN, false, false>)
                         : extendNodes == NODES_PACKED_LDS
                             ? (wt ? rt_wf_extend_kernel<NODES_PACKED_LDS, true, false>
