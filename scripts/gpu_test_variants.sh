@@ -16,6 +16,8 @@ RT_WF_ROWS=1 \
 # (4) the -DRT_DEBUG_WALK build (make debugwalk): links and leaf ranges checked inside every kernel that walks the tree
 RT_HIP_LIB=$PWD/raytracer_amd/lib/variants/librt_hip_debugwalk.so \
   timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread | tail -2
-# (5) the packed-fp32 pair tests (used by default only beyond the L2s) forced onto every packed scene
+# (5) the packed-fp32 pair tests (opt-in) on every packed scene; (6) the contiguous block order of the filter passes everywhere
 RT_WF_PAIRS=1 \
+  timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread | tail -2
+RT_FILTER_MAP=1 \
   timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread | tail -2

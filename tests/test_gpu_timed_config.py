@@ -210,24 +210,27 @@ def bench_shape(scene, frames, want_dense, in_flight_setting=0):
         assert np.array_equal(read.view(np.uint16), got["filtered"].view(np.uint16))   # the same chain as the queued one
     finally:
         ctx.close()
-    # --- the schedule that ran is the timed one
-    alone = in_flight_setting == 1
-    assert in_flight == (1 if alone else 4)
-    for s in schedules:
-        assert s["walk_settled"] == 1 and s["have_prediction"] == 1 and s["flat_record"] == 1 and s["node_fetch"] == 2, s
-        assert s["stages"] == mb + 1
-        if alone:   # one frame at a time: four extend blocks per CU, sparse stages in the row-mode kernel (by prediction)
-            assert s["pipelined"] == 0 and s["frames_in_flight"] == 1 and s["fill"] == 2 and s["extend_blocks_per_cu"] == 4, s
-            assert s["dense"] == (1 if want_dense else 0) and (want_dense or s["rows_stage_mask"] != 0), s
-        else:       # frames in flight: two blocks per CU and no row mode (three blocks on dense frames)
-            assert s["pipelined"] == 1 and s["frames_in_flight"] == 4 and s["fill"] == 1 and s["rows_stage_mask"] == 0, s
-            assert (s["dense"], s["extend_blocks_per_cu"]) == ((1, 3) if want_dense else (0, 2)), s
-    assert sorted({s["lane"] for s in schedules}) == ([0] if alone else list(range(min(4, frames))))
-    if alone and not want_dense:
-        assert cnt.rows_rays > 0 and cnt.rows_node_visits > 0 and cnt.rows_tri_tests > 0
-    else:
-        assert cnt.rows_rays == 0
-    assert levels is not None
+    # --- the schedule that ran is the timed one (not when a development knob pins part of the schedule, as in the runs
+    # of scripts/gpu_test_variants.sh: the comparison with the oracle below is then the whole test)
+    pinned = any(k.startswith("RT_WF_") or k in ("RT_PIPELINE", "RT_FILTER_CELLS") for k in os.environ)
+    if not pinned:
+        alone = in_flight_setting == 1
+        assert in_flight == (1 if alone else 4)
+        for s in schedules:
+            assert s["walk_settled"] == 1 and s["have_prediction"] == 1 and s["flat_record"] == 1 and s["node_fetch"] == 2, s
+            assert s["stages"] == mb + 1
+            if alone:   # one frame at a time: four extend blocks per CU, sparse stages in the row-mode kernel (by prediction)
+                assert s["pipelined"] == 0 and s["frames_in_flight"] == 1 and s["fill"] == 2 and s["extend_blocks_per_cu"] == 4, s
+                assert s["dense"] == (1 if want_dense else 0) and (want_dense or s["rows_stage_mask"] != 0), s
+            else:       # frames in flight: two blocks per CU and no row mode (three blocks on dense frames)
+                assert s["pipelined"] == 1 and s["frames_in_flight"] == 4 and s["fill"] == 1 and s["rows_stage_mask"] == 0, s
+                assert (s["dense"], s["extend_blocks_per_cu"]) == ((1, 3) if want_dense else (0, 2)), s
+        assert sorted({s["lane"] for s in schedules}) == ([0] if alone else list(range(min(4, frames))))
+        if alone and not want_dense:
+            assert cnt.rows_rays > 0 and cnt.rows_node_visits > 0 and cnt.rows_tri_tests > 0
+        else:
+            assert cnt.rows_rays == 0
+        assert levels is not None
     # --- the picture is the oracle's
     ref = orclib.trace(orclib.Scene(wl.buffers), W, H, wl.rays, wl.eye, spp=spp * frames, max_bounces=mb)
     assert np.array_equal(got["normal"], ref["normal"])
