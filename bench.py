@@ -58,12 +58,16 @@ def cpu_baseline(wl, spp, max_bounces, filter_iters, max_follows=1000, budget_s=
     per_row = (time.time() - t) / probe_rows
     rows = H if per_row * H * spp < budget_s else max(probe_rows, int(budget_s / (per_row * spp)))
     y0 = (H - rows) // 2
-    # a frame that is mostly sky takes a fraction of a second: repeat it until about half the budget is used
-    repeats = 1 if rows < H else int(min(64, max(1, (0.5 * budget_s) // max(per_row * H * spp, 1e-3))))
+    # a frame that is mostly sky takes a fraction of a second (the probe rows are the busiest ones): repeat it until a
+    # fifth of the budget has passed on the wall clock, i.e. 16 threads x 3-5 s of CPU work
+    repeats = 0
     t = time.time()
-    for _ in range(repeats):
+    while True:
         o = orclib.trace(sc, W, H, wl.rays, wl.eye, spp=spp, max_bounces=max_bounces, rect=(0, y0, W, y0 + rows),
                          max_follows=max_follows)
+        repeats += 1
+        if rows < H or repeats >= 256 or time.time() - t >= 0.2 * budget_s:
+            break
     t_trace = (time.time() - t) / repeats
     rays = int(o["stats_sum"][..., 0].sum())
     t = time.time()
