@@ -172,6 +172,46 @@ def test_png_writer(tmp_path):
     assert np.array_equal(raw[:, 1:].reshape(37, 53, 4), img[::-1])  # flipped like stbi_flip_vertically_on_write
 
 
+def _png_pixels(path):
+    data = open(path, "rb").read()
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(typ + body) == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        if typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    w, h = ihdr[:2]
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + w * 4)
+    return raw[:, 1:].reshape(h, w, 4), len(data)
+
+
+def test_png_writer_compresses_what_a_frame_looks_like(tmp_path):
+    """The writer deflates (fixed Huffman code over LZ77 matches, raytracer_amd/host/png_write.cpp): a frame that is mostly
+    flat sky with a noisy object in the middle comes back pixel for pixel from zlib's inflate and is a small fraction of
+    its raw size; sizes around the match-length and window limits round-trip too."""
+    rng = np.random.default_rng(1)
+    img = np.empty((360, 640, 4), np.uint8)
+    img[:] = (227, 245, 255, 255)
+    img[120:240, 200:440] = rng.integers(0, 256, (120, 240, 4), dtype=np.uint8)
+    img[300:, :, 0] = np.arange(640, dtype=np.uint8)[None, :]
+    p = str(tmp_path / "frame.png")
+    hostlib.write_png(p, img, flip=False)
+    back, size = _png_pixels(p)
+    assert np.array_equal(back, img)
+    assert size < 0.2 * img.nbytes
+    for w, h in ((1, 1), (2, 1), (64, 1), (65, 3), (8191, 2), (8200, 5)):
+        small = np.zeros((h, w, 4), np.uint8)
+        small[..., 1] = (np.arange(w) // 3 % 251).astype(np.uint8)[None, :]
+        small[..., 3] = 255
+        hostlib.write_png(p, small, flip=True)
+        back, _ = _png_pixels(p)
+        assert np.array_equal(back, small[::-1]), (w, h)
+
+
 def test_pcg32_known_answers():
     """PCG XSH-RR 64/32 of the lattice generator: the published outputs of pcg32_srandom(42, 54)."""
     L = hostlib.lib()
