@@ -3,9 +3,11 @@ import sys
 
 import pytest
 
-# PyTorch-ROCm bundles its own HIP runtime and RCCL (same sonames as /opt/rocm's).  Some tests use torch next to the
-# launcher; the process must then load torch's copies FIRST ("PyTorch in the same process"): loaded
-# after librt_hip.so / librccl.so.1 of /opt/rocm, the two sets of libraries end in a double free at interpreter exit.
+# PyTorch-ROCm bundles its own HIP runtime and RCCL (same sonames as /opt/rocm's).  Some tests use torch.cuda next to the
+# launcher; for torch.cuda to be usable in such a process torch's copies must be the ones loaded, i.e. torch is imported
+# FIRST ("PyTorch in the same process").  Either order exits cleanly since round 3 (the launcher opens RCCL
+# RTLD_LOCAL after probing for a loaded copy: tests/test_rccl_import_order.py runs both orders in child processes); in
+# the other order torch.cuda merely reports no device.
 import torch  # noqa: F401,E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
