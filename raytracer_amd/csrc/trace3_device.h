@@ -197,15 +197,28 @@ __device__ __forceinline__ float randomTriangleAreaDirectionPDF(f3 p, const Ligh
 
 // ---------------------------------------------------------------- leaf test
 // One 36-byte triangle record {v0, e1, e2} (rt_device.h: tris36) as three float4 (w = 0): two 16-byte loads and one
-// 4-byte load at 4-byte alignment, which gfx950's global loads accept.
+// 4-byte load at 4-byte alignment, which gfx950's global loads accept — the form with the fewest clocks on the
+// vector-memory return path, for kernels that are bound by it (the extend kernel: DESIGN.md 4.2; the per-pixel kernel:
+// room.obj 45.7 -> 41.1 ms per frame).  A translation unit that defines RT_TRI_LOAD_NARROW gets three 12-byte loads
+// instead: the Q-table kernel waits for single loads (it spends 91 % of its cycles in s_waitcnt) and loses 7 % with the
+// 16-byte loads at odd alignment (165 against 159 ms per room.obj frame; 158 with round 2's padded records).
 typedef float rt_f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float rt_f3u __attribute__((ext_vector_type(3), aligned(4)));
 __device__ __forceinline__ void loadTri36(const float *__restrict__ tris36, int i, float4 &a0, float4 &a1, float4 &a2) {
     const float *p = tris36 + 9 * (size_t)i;
+#ifdef RT_TRI_LOAD_NARROW
+    const rt_f3u x = *reinterpret_cast<const rt_f3u *>(p), y = *reinterpret_cast<const rt_f3u *>(p + 3),
+                 z = *reinterpret_cast<const rt_f3u *>(p + 6);
+    a0 = make_float4(x.x, x.y, x.z, 0.0f);
+    a1 = make_float4(y.x, y.y, y.z, 0.0f);
+    a2 = make_float4(z.x, z.y, z.z, 0.0f);
+#else
     const rt_f4u lo = *reinterpret_cast<const rt_f4u *>(p), hi = *reinterpret_cast<const rt_f4u *>(p + 4);
     const float last = p[8];
     a0 = make_float4(lo.x, lo.y, lo.z, 0.0f);
     a1 = make_float4(lo.w, hi.x, hi.y, 0.0f);
     a2 = make_float4(hi.z, hi.w, last, 0.0f);
+#endif
 }
 // intersectTriangle (geometry.glsl:31-51) on one {v0, e1, e2} record; e1, e2 were subtracted at upload
 // with the same fp32 operations.  Updates the closest hit with the strict `<` of trace3.cs:177.

@@ -26,6 +26,7 @@
 // Staging the cells of all objects in LDS (48 KB for room.obj) was measured twice and is slower than reading
 // them through L1 (440 vs 295 ms before, 198 vs 150 ms after the other changes), so it is not done.
 #define RT_DEBUG_WALK_EXPORT rt_debug_walk_violations_rl
+#define RT_TRI_LOAD_NARROW // (trace3_device.h: loadTri36)
 #include "trace3_device.h"
 
 #include "trace3_rl.h"
