@@ -327,10 +327,18 @@ typedef struct rt_schedule_info {
 } rt_schedule_info;
 int rt_last_schedule(const rt_ctx *ctx, rt_schedule_info *out);
 
+/* Where the most recent rt_filter left RT_IMAGE_FILTERED (no counterpart in the reference; for tests and benchmarks): the
+ * index of the lane whose own buffers hold it — the filter of a whole frame that was just traced with frames in flight
+ * keeps everything its passes after the first touch on that frame's lane, so that the next frame's last kernel waits
+ * for its first pass only — or -1: the context's buffers (every other case; also before any rt_filter).  Readers of
+ * RT_IMAGE_FILTERED see the same image either way. */
+int rt_filtered_lane(const rt_ctx *ctx);
+
 /* Frames in flight (no counterpart in the reference, whose GL queue is one stream): with n > 1 (default 4), successive
  * rt_trace_batch calls of RT_KERNEL_TRACE3 rotate over n internal streams ("lanes"), each with its own pipeline memory:
  * frame k+1 is traced while frame k is still being traced / filtered, and only its last kernel, which writes colour,
- * normals and positions, waits for everything queued before the call.  The images a caller reads are the same as with
+ * normals and positions, waits for everything queued before the call (after an rt_filter of the whole frame traced
+ * just before: for that filter's first pass, rt_filtered_lane).  The images a caller reads are the same as with
  * n = 1; what changes is the latency hidden (sparse frames leave most of the GPU idle in the tail of every stage) and
  * the memory held (508 B per pixel-sample and lane; lanes are not used when they would need more than 48 GB together).
  * Not used with RT_FLAG_AUX / RT_FLAG_PIXEL_STATS, on a caller-supplied stream, or while the launcher times its

@@ -214,6 +214,9 @@ int rt_gather_tiles(rt_ctx *c, int image, const rt_rect *rects, int nrects, int 
     }
 
     // 1. trace stream: once gather k-2 has left this staging buffer, pack the tile (rows of the image -> dense rows)
+    // (the pack reads an image the next frame's commit overwrites, unless it is a lane's own filtered image: that commit
+    // waits for everything queued here, not just for the filter's first pass — rt_filter)
+    if (!(image == RT_IMAGE_FILTERED && c->filteredLane >= 0)) c->earlyFence = nullptr;
     if (m.used[k]) HIP_TRY(c, hipStreamWaitEvent(c->stream, m.done[k], 0));
     if (bytesOf(mine)) {
         const char *imgAt = (const char *)im.p + ((size_t)mine.y0 * c->width + mine.x0) * pb;

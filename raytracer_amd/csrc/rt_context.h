@@ -53,6 +53,18 @@ struct rt_ctx {
     int width = 0, height = 0;
     DevBuf color, normal, pos, filt[2], tridx, visits, stats, ldr;
     int filteredIndex = -1; // which of filt[] holds the result of the last rt_filter
+    int tuneFilterLane = -1; // RT_FILTER_LANE=0: never the lane-private form of rt_filter
+    int tuneFilterFence = 0; // RT_FILTER_FENCE=j: the event the next commit waits for is recorded behind pass j (0 = the first)
+    int filteredLane = -1;  // ... of lane[filteredLane].filt[] when >= 0 (a filter that ran lane-private), else of the context's
+    int levelLane = -1;     // likewise for the cell levels of that filter (rt_flat_cells)
+    // The frame the last rt_trace / rt_trace_batch left in the images, when it was traced with frames in flight: its
+    // lane and tile.  rt_filter may then read that lane's staged normals / positions instead of the committed images.
+    int lastTraceLane = -1;
+    rt_rect lastTraceRect = {0, 0, 0, 0};
+    // Set by a lane-private rt_filter, consumed by the next pipelined trace: the event its commit (the blend kernel)
+    // waits for instead of "everything queued so far" — the filter's first pass, the last kernel that reads what the
+    // commit overwrites.  Dropped by every other entry point (rtJoinLanes).
+    hipEvent_t earlyFence = nullptr;
     // Flat cells (rt_device.h: RtFlatCells).  flatFlag / flatColor / flatNormal / flatPos: what the last wavefront
     // frame's blend kernel recorded; flatLevel / flatTexels: what the last rt_filter derived from it (levels and the
     // per-cell results of its passes).  flatValid: the record describes colour, normals and positions as they are
@@ -74,6 +86,10 @@ struct rt_ctx {
         DevBuf stageNormal, stagePos;   // the frame's G-buffer until its last kernel commits it
         size_t wfCapacity = 0, wfRadianceSlots = 0;
         hipEvent_t tick = nullptr;      // recorded on the lane's stream when the other lane (or a join) needs to wait for it
+        // A filter of a frame traced on this lane keeps what its later passes read and write on the lane (rt_filter):
+        // ping-pong outputs, cell levels and per-cell results; fence = recorded behind its first pass.
+        DevBuf filt[2], flatLevel, flatTexels, flatPatch;
+        hipEvent_t fence = nullptr;
         bool dirty = false;             // the launcher moved on to another lane while this one held work not yet joined
     } lane[RT_MAX_LANES];
     int laneNow = 0;                    // lane of the stream that `stream` currently is (when it is one of ours)
@@ -222,7 +238,8 @@ inline ImageRef imageOf(rt_ctx *c, int image) {
     case RT_IMAGE_COLOR: return {c->color.p, 16};
     case RT_IMAGE_NORMAL: return {c->normal.p, 4};
     case RT_IMAGE_POSITION: return {c->pos.p, 8};
-    case RT_IMAGE_FILTERED: return {c->filteredIndex >= 0 ? c->filt[c->filteredIndex].p : nullptr, 8};
+    case RT_IMAGE_FILTERED:
+        return {c->filteredIndex < 0 ? nullptr : c->filteredLane >= 0 ? c->lane[c->filteredLane].filt[c->filteredIndex].p : c->filt[c->filteredIndex].p, 8};
     case RT_IMAGE_TRIDX: return {c->tridx.p, 4};
     case RT_IMAGE_VISITS: return {c->visits.p, 4};
     case RT_IMAGE_STATS: return {c->stats.p, 16};

@@ -135,6 +135,10 @@ void spanStop(rt_ctx *c, TimedSpan &s, hipStream_t stream = nullptr) {
 // Orders the context's current stream after whatever the lanes' streams still hold (two frames in flight): called by
 // every entry point that reads or writes what a frame reads or writes, except the pipelined trace and the filter.
 int rtJoinLanes(rt_ctx *c) {
+    // (whatever calls this may queue work that reads or writes the images: the next commit waits for all of it, and a
+    // filter can no longer assume that a lane's staged G-buffer is what the images hold)
+    c->earlyFence = nullptr;
+    c->lastTraceLane = -1;
     for (rt_ctx::Lane &L : c->lane) {
         // (a lane that was never left with work on it — every lane of a context that has not had frames in flight —
         // needs no event: the call then touches no stream but the current one, e.g. a caller's stream under capture)
@@ -242,6 +246,8 @@ int rt_last_schedule(const rt_ctx *c, rt_schedule_info *out) {
     return RT_OK;
 }
 
+int rt_filtered_lane(const rt_ctx *c) { return c && c->filteredIndex >= 0 ? c->filteredLane : -1; }
+
 size_t rt_image_pixel_bytes(int image) {
     switch (image) {
     case RT_IMAGE_COLOR: case RT_IMAGE_STATS: return 16;
@@ -301,6 +307,7 @@ int rt_create(int device_id, rt_ctx **out) {
         rt_ctx::Lane &L = c->lane[k];
         if (k && hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) L.stream = nullptr;
         if (L.stream && hipEventCreateWithFlags(&L.tick, hipEventDisableTiming) != hipSuccess) L.tick = nullptr;
+        if (L.stream && hipEventCreateWithFlags(&L.fence, hipEventDisableTiming) != hipSuccess) L.fence = nullptr;
         if (k && (!L.stream || !L.tick)) break;
         lanes = k + 1;
     }
@@ -334,6 +341,8 @@ int rt_create(int device_id, rt_ctx **out) {
     for (int i = 0; i < RT_MAX_FLAT_PATCHES; ++i) c->hostFlatPatch[i] = -1;
     if (const char *e = std::getenv("RT_FILTER_CELLS")) c->useFlatCells = std::atoi(e) != 0;
     if (const char *e = std::getenv("RT_FILTER_MAP")) c->tuneFilterMap = std::max(-1, std::min(1, std::atoi(e)));
+    if (const char *e = std::getenv("RT_FILTER_LANE")) c->tuneFilterLane = std::max(-1, std::min(1, std::atoi(e)));
+    if (const char *e = std::getenv("RT_FILTER_FENCE")) c->tuneFilterFence = std::max(0, std::min(30, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_REFILL")) c->tuneRefillLanes = std::max(1, std::min(64, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_CACHE_NODES")) c->tuneCacheNodes = std::max(0, std::min(3800, std::atoi(e)));
     if (const char *e = std::getenv("RT_WF_RAYS_PER_WAVE")) c->tuneRaysPerWave = std::max(0, std::min(64, std::atoi(e)));
@@ -385,9 +394,11 @@ void rt_destroy(rt_ctx *c) {
     for (rt_ctx::Lane &L : c->lane) {
         for (DevBuf &b : L.wfState) releaseBuf(b);
         for (DevBuf &b : L.wfRay) releaseBuf(b);
-        DevBuf *mine[] = {&L.wfQueue[0], &L.wfQueue[1], &L.wfCounts, &L.wfRadiance, &L.wfPrimPix, &L.stageNormal, &L.stagePos};
+        DevBuf *mine[] = {&L.wfQueue[0], &L.wfQueue[1], &L.wfCounts, &L.wfRadiance, &L.wfPrimPix, &L.stageNormal, &L.stagePos,
+                          &L.filt[0], &L.filt[1], &L.flatLevel, &L.flatTexels, &L.flatPatch};
         for (DevBuf *b : mine) releaseBuf(*b);
         if (L.tick) (void)hipEventDestroy(L.tick);
+        if (L.fence) (void)hipEventDestroy(L.fence);
     }
     for (int k = 1; k < RT_MAX_LANES; ++k)
         if (c->lane[k].stream) (void)hipStreamDestroy(c->lane[k].stream);
@@ -412,6 +423,8 @@ int rt_set_stream(rt_ctx *c, void *hip_stream) {
         L.dirty = false; // (drained: nothing left to join)
     }
     c->chainValid = false;
+    c->earlyFence = nullptr;
+    c->lastTraceLane = -1;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->ownStream;
     c->laneNow = 0;
     return RT_OK;
@@ -629,6 +642,7 @@ int rt_clear(rt_ctx *c) {
     HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, n * 16, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->ldr.p, 0, n * 4, c->stream));
     c->filteredIndex = -1;
+    c->filteredLane = c->levelLane = -1;
     c->flatValid = false;
     c->filterUsedFlat = false;
     return RT_OK;
@@ -995,6 +1009,10 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             rt_ctx::Lane &prev = c->lane[c->laneNow];
             HIP_TRY(c, hipEventRecord(prev.tick, c->stream));
             before = prev.tick;
+            // (a lane-private filter was the last thing queued: only its first pass reads what this frame's commit
+            // overwrites, rt_filter)
+            if (c->earlyFence) before = c->earlyFence;
+            c->earlyFence = nullptr;
             prev.dirty = true; // left with work on it: later joins must wait for it
             c->laneNow = (c->laneNow + 1) % lanes;
             c->stream = c->lane[c->laneNow].stream;
@@ -1025,6 +1043,8 @@ int rt_trace_batch(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
             c->flatValid = true;
             c->flatRect = r;
         }
+        c->lastTraceLane = (rc == RT_OK && pipelined) ? c->laneNow : -1;
+        c->lastTraceRect = r;
         return rc;
     }
     case RT_KERNEL_TRACE3_RL: {
@@ -1273,6 +1293,33 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
                std::min(target.y1 + reach, c->height) <= c->flatRect.y1;
     }
     const int cellsX = (c->width + 15) >> RT_CELL_SHIFT, cellsY = (c->height + 15) >> RT_CELL_SHIFT;
+    // Frames in flight: the next frame's commit (its blend kernel, on the next lane) overwrites colour, normals, positions
+    // and the flat-cell record, so it has to wait for whatever reads them here.  When this call filters the whole frame
+    // that was just traced on the current lane, only the levels kernel and the first pass need to: the later passes take
+    // normals and positions from the lane's staging copies (what the commit copied into the images, bit for bit), and
+    // ping-pong outputs, cell levels and per-cell results are the lane's own.  An event behind the first pass is then all
+    // the next commit waits for (rt_trace_batch), and passes 1.. run beside the next frame's blend instead of before it.
+    // The next kernels to write any of the lane's buffers are this lane's own, `frames in flight` frames later.
+    const rt_rect whole = fullRect(c);
+    auto same = [](const rt_rect &a, const rt_rect &b) { return a.x0 == b.x0 && a.y0 == b.y0 && a.x1 == b.x1 && a.y1 == b.y1; };
+    const int mineLane = c->lastTraceLane;
+    bool onLane = c->tuneFilterLane != 0 && iterations >= 2 && mineLane >= 0 && mineLane == c->laneNow &&
+                  c->stream == c->lane[mineLane].stream && c->lane[mineLane].fence && c->lane[mineLane].stageNormal.p &&
+                  same(target, whole) && same(c->lastTraceRect, whole);
+    DevBuf *filt = c->filt, *flatLevel = &c->flatLevel, *flatTexels = &c->flatTexels, *flatPatch = &c->flatPatch;
+    if (onLane) {
+        rt_ctx::Lane &L = c->lane[mineLane];
+        const size_t px = (size_t)c->width * c->height, cellCount = (size_t)cellsX * cellsY;
+        if ((rc = ensure(c, L.filt[0], px * 8)) || (rc = ensure(c, L.filt[1], px * 8))) return rc;
+        if (flat && ((rc = ensure(c, L.flatLevel, cellCount)) || (rc = ensure(c, L.flatTexels, cellCount * 8 * RT_FLAT_MAX_PASSES)) ||
+                     (rc = ensure(c, L.flatPatch, 4 * (size_t)rtFlatPatches(cellsX, cellsY)))))
+            return rc;
+        filt = L.filt;
+        flatLevel = &L.flatLevel;
+        flatTexels = &L.flatTexels;
+        flatPatch = &L.flatPatch;
+    }
+    c->earlyFence = nullptr;
     if (flat) {
         float cp[RT_FLAT_MAX_PASSES], np[RT_FLAT_MAX_PASSES], pp[RT_FLAT_MAX_PASSES];
         for (int i = 0; i < iterations; ++i) { // (the same expressions as in the loop below)
@@ -1288,12 +1335,13 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
         rec.cellsX = cellsX;
         rec.cellsY = cellsY;
         SpanGuard span(c, TK_FILTER);
-        hipError_t e = rtLaunchFlatLevels(rec, (uint8_t *)c->flatLevel.p, (uint2 *)c->flatTexels.p, (int *)c->flatPatch.p, c->width, c->height,
+        hipError_t e = rtLaunchFlatLevels(rec, (uint8_t *)flatLevel->p, (uint2 *)flatTexels->p, (int *)flatPatch->p, c->width, c->height,
                                           iterations, cp, np, pp, c->stream);
         span.end();
         if (e != hipSuccess) return hipFail(c, e, "flat levels launch");
     }
     c->filterUsedFlat = flat;
+    c->levelLane = onLane ? mineLane : -1;
     // Block order of the passes (filter_kernel.hip: rt_atrous_kernel).  With many flat cells the order that spreads the
     // tiles which cannot use them over the XCDs; otherwise the order that gives each XCD one contiguous part of the image,
     // so that the texels neighbouring tiles share are fetched from HBM once (measured on room.obj: 2.3 x the compulsory
@@ -1328,24 +1376,31 @@ int rt_filter(rt_ctx *c, int iterations, float c_phi0, float n_phi0, float p_phi
         r.y1 = target.y1 + grow > c->height ? c->height : target.y1 + grow;
         RtFilterCells cells{};
         if (flat) {
-            cells.level = (const uint8_t *)c->flatLevel.p;
-            cells.texel = (const uint2 *)c->flatTexels.p + (size_t)i * cellsX * cellsY;
+            cells.level = (const uint8_t *)flatLevel->p;
+            cells.texel = (const uint2 *)flatTexels->p + (size_t)i * cellsX * cellsY;
             cells.cellsX = cellsX;
             cells.pass = i;
         }
         SpanGuard span(c, TK_FILTER);
-        hipError_t e = rtLaunchAtrous(readF32, readF16, (const uint32_t *)c->normal.p, (const uint2 *)c->pos.p,
-                                      (uint2 *)c->filt[write].p, c->width, c->height, r, c_phi, n_phi, p_phi, step,
+        const bool staged = onLane && i > 0;
+        hipError_t e = rtLaunchAtrous(readF32, readF16, (const uint32_t *)(staged ? c->lane[mineLane].stageNormal.p : c->normal.p),
+                                      (const uint2 *)(staged ? c->lane[mineLane].stagePos.p : c->pos.p),
+                                      (uint2 *)filt[write].p, c->width, c->height, r, c_phi, n_phi, p_phi, step,
                                       cells, locality, c->stream);
         span.end();
         if (e != hipSuccess) return hipFail(c, e, "atrous launch");
         readF32 = nullptr;
-        readF16 = (const uint2 *)c->filt[write].p;
+        readF16 = (const uint2 *)filt[write].p;
         c->filteredIndex = write;
+        c->filteredLane = onLane ? mineLane : -1;
         write ^= 1;
+        if (onLane && i == std::min(c->tuneFilterFence, iterations - 1)) {
+            HIP_TRY(c, hipEventRecord(c->lane[mineLane].fence, c->stream));
+            c->earlyFence = c->lane[mineLane].fence;
+        }
     }
     if (flat && patches <= RT_MAX_FLAT_PATCHES) // for a later call's choice of block order (above)
-        HIP_TRY(c, hipMemcpyAsync(c->hostFlatPatch, c->flatPatch.p, (size_t)patches * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->hostFlatPatch, flatPatch->p, (size_t)patches * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     return RT_OK;
 }
 
@@ -1356,7 +1411,7 @@ int rt_flat_cells(rt_ctx *c, int which, uint8_t *flags, size_t nbytes) {
     if (nbytes != need) return fail(c, RT_EINVAL, "rt_flat_cells: size mismatch, need " + std::to_string(need));
     const void *src = nullptr;
     if (which == 0 && c->flatValid) src = c->flatFlag.p;
-    if (which == 1 && c->filterUsedFlat && c->filteredIndex >= 0) src = c->flatLevel.p;
+    if (which == 1 && c->filterUsedFlat && c->filteredIndex >= 0) src = c->levelLane >= 0 ? c->lane[c->levelLane].flatLevel.p : c->flatLevel.p;
     if (!src) return fail(c, RT_ESTATE, "rt_flat_cells: no such record");
     int rc = bind(c);
     if (rc) return rc;
@@ -1376,7 +1431,7 @@ int rt_tonemap(rt_ctx *c, int source_image, float exposure, const rt_rect *tile)
     if (source_image == RT_IMAGE_COLOR) f32 = (const float4 *)c->color.p;
     else if (source_image == RT_IMAGE_FILTERED) {
         if (c->filteredIndex < 0) return fail(c, RT_ESTATE, "rt_tonemap: no filtered image yet");
-        f16 = (const uint2 *)c->filt[c->filteredIndex].p;
+        f16 = (const uint2 *)imageOf(c, RT_IMAGE_FILTERED).p;
     } else if (source_image == RT_IMAGE_ASSEMBLED) { // the frame rt_gather_tiles put together: RGBA32F or RGBA16F
         if (!c->assembled.p || (c->assembledPixelBytes != 16 && c->assembledPixelBytes != 8))
             return fail(c, RT_ESTATE, "rt_tonemap: no assembled colour frame yet");

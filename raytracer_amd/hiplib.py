@@ -82,7 +82,7 @@ EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_uplo
            "rt_clear", "rt_trace", "rt_trace_batch", "rt_trace_batch_static", "rt_static_max_paths", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
            "rt_readback_rect_device", "rt_write_rect_device", "rt_write_rect_device_async", "rt_write_image", "rt_image_pixel_bytes",
            "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
-           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_gather_tiles", "rt_walk_stop", "rt_last_schedule", "rt_set_frames_in_flight", "rt_frames_in_flight", "rt_flat_cells",
+           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_gather_tiles", "rt_walk_stop", "rt_last_schedule", "rt_filtered_lane", "rt_set_frames_in_flight", "rt_frames_in_flight", "rt_flat_cells",
            "rt_work_group_size", "rt_version"]
 
 _lib = None
@@ -134,6 +134,7 @@ def lib():
         L.rt_gather_tiles.argtypes = [vp, i32, rp, i32, i32]
         L.rt_walk_stop.argtypes = [vp]
         L.rt_last_schedule.argtypes = [vp, ctypes.POINTER(ScheduleInfo)]
+        L.rt_filtered_lane.argtypes = [vp]
         L.rt_set_frames_in_flight.argtypes = [vp, i32]
         L.rt_frames_in_flight.argtypes = [vp]
         L.rt_flat_cells.argtypes = [vp, ctypes.c_int, vp, ctypes.c_size_t]
@@ -334,6 +335,10 @@ class Context:
             return None
         self._check(r, "rt_last_schedule")
         return si
+
+    def filtered_lane(self):
+        """rt_filtered_lane: the lane whose own buffers hold the last rt_filter's image, -1 = the context's."""
+        return int(lib().rt_filtered_lane(self._h))
 
     def frames_in_flight(self):
         return int(lib().rt_frames_in_flight(self._h))

@@ -21,3 +21,6 @@ RT_WF_PAIRS=1 \
   timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread | tail -2
 RT_FILTER_MAP=1 \
   timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread | tail -2
+# (7) rt_filter never in its lane-private form (the next frame's last kernel then waits for every pass)
+RT_FILTER_LANE=0 \
+  timeout -k 10 700 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread | tail -2

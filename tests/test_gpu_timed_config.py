@@ -267,3 +267,65 @@ def test_bench_shape_one_frame_at_a_time_against_oracle():
 def test_bench_shape_dense_frame_against_oracle():
     """cases.room: every pixel sees geometry -> stages of millions of rays -> three extend blocks per CU, no row mode."""
     bench_shape("room", 5, want_dense=True)
+
+
+# ---------------------------------------------------------------------------- the filter of a frame in flight, on its lane
+@pytest.mark.parametrize("scene,tail", [("scene", 1), ("scene", 3), ("room", 2)])
+def test_filter_on_the_lane_is_not_disturbed_by_the_frames_behind_it(scene, tail):
+    """With frames in flight the filter of a whole frame keeps what its passes after the first read and write on the
+    frame's lane, and the next frame's last kernel (which rewrites colour, normals, positions and the flat-cell record)
+    waits for the filter's first pass only (rt_launcher.hip: rt_filter).  Here frame 1 is filtered and `tail` further
+    frames are traced behind it WITHOUT a sync, so that their commits run beside its later passes; RT_IMAGE_FILTERED
+    must then be, bit for bit, the filter of frame 1 made with nothing in flight (the context's buffers, lanes joined
+    before and after), and the images those of all the frames."""
+    W, H, spp, mb, iters = 1920, 1080, 4, 5, 5
+    wl = workloads.Workload(scene, W, H)
+    ctx = make_ctx()
+    try:
+        ctx.upload_scene(wl.buffers)
+        ctx.resize(W, H)
+
+        def trace(k):
+            ctx.trace_samples(wl.rays, wl.eye, spp=spp, frame0=spp * k, max_bounces=mb, flags=0, num_emitters=wl.num_emitters)
+
+        settle = 0
+        while ctx.walk_stop() == 0 and settle < 8:
+            trace(0)
+            ctx.filter(iters)
+            settle += 1
+        ctx.sync()
+        # --- the reference: one step at a time
+        ctx.clear()
+        trace(0)
+        trace(1)
+        ctx.readback(hiplib.IMAGE_NORMAL)            # (joins the lanes: the filter below runs on the context's buffers)
+        ctx.filter(iters)
+        assert ctx.filtered_lane() == -1
+        want = ctx.readback(hiplib.IMAGE_FILTERED)
+        want_levels = ctx.flat_cells(1)
+        for k in range(2, 2 + tail):
+            trace(k)
+        want_color = ctx.readback(hiplib.IMAGE_COLOR)
+        # --- the same frames back to back
+        ctx.clear()
+        trace(0)
+        ctx.filter(iters)
+        trace(1)
+        lane = ctx.last_schedule().lane
+        ctx.filter(iters)
+        on_lane = ctx.filtered_lane()
+        for k in range(2, 2 + tail):
+            trace(k)
+        got = ctx.readback(hiplib.IMAGE_FILTERED)
+        got_levels = ctx.flat_cells(1)
+        got_color = ctx.readback(hiplib.IMAGE_COLOR)
+        in_flight = ctx.frames_in_flight()
+    finally:
+        ctx.close()
+    if "RT_FILTER_LANE" not in os.environ and "RT_PIPELINE" not in os.environ and in_flight > 1:
+        assert on_lane == lane and lane >= 0
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
+    assert (got_levels is None) == (want_levels is None)
+    if got_levels is not None:
+        assert np.array_equal(got_levels, want_levels)
+    assert np.array_equal(got_color.view(np.uint32), want_color.view(np.uint32))
