@@ -18,8 +18,12 @@ struct DevBuf {
 
 enum TimeKind { TK_TRACE = RT_TIME_TRACE, TK_FILTER = RT_TIME_FILTER, TK_TONEMAP = RT_TIME_TONEMAP };
 
-#define RT_MAX_LANES 4
-#define RT_DEFAULT_LANES 4 // measured 1 / 2 / 3 / 4 / 5 / 6: 1.65 / 1.09 / 0.95 / 0.90 / 1.04 / 1.04 ms per metric frame (a process has 4 hardware queues)
+#define RT_MAX_LANES 8
+// measured in round 2, 1 / 2 / 3 / 4 / 5 / 6 lanes: 1.65 / 1.09 / 0.95 / 0.90 / 1.04 / 1.04 ms per metric frame — a process has 4
+// hardware queues (GPU_MAX_HW_QUEUES) and two lanes that share one run one after the other.  With 8 queues (round 3):
+// 4 / 8 / 12 lanes 0.785 / 0.722 / 0.72 ms in a long run of frames, but 0.77-0.81 / 0.80-0.82 for a burst of 20 between
+// two syncs (twice the lanes to fill and drain): 5 .. 8 are the caller's to ask for, the default stays 4.
+#define RT_DEFAULT_LANES 4
 
 struct TimedSpan {
     hipEvent_t start, stop;

@@ -271,7 +271,7 @@ int rt_frames_in_flight(const rt_ctx *c) { return c ? lanesInUse(c) : 0; }
 
 int rt_set_frames_in_flight(rt_ctx *c, int n) {
     if (!c) return RT_EINVAL;
-    if (n < 0 || n > RT_MAX_LANES) return fail(c, RT_EINVAL, "rt_set_frames_in_flight: 1 .. 4, or 0 for the launcher's choice");
+    if (n < 0 || n > RT_MAX_LANES) return fail(c, RT_EINVAL, "rt_set_frames_in_flight: 1 .. 8, or 0 for the launcher's choice");
     int rc = bind(c);
     if (rc) return rc;
     if ((rc = rtJoinLanes(c))) return rc;

@@ -8,7 +8,7 @@ python - "$TAG" <<'PY'
 import json, sys
 d = json.load(open(f"gpurun_out/bench_{sys.argv[1]}.json"))
 print({k: d.get(k) for k in ("value", "ms_per_step", "frames_in_flight", "latency_ms_one_frame", "ms_per_frame_one_frame_at_a_time")})
-print(d.get("kernel_ms_per_frame_max_rank"))
+print(d.get("kernel_ms_per_frame_max_rank"), "steady", {k: (d.get("steady_state") or {}).get(k) for k in ("frames_in_flight", "ms_per_frame", "error")})
 r = d.get("roofline") or {}
 print("roofline", {k: r.get(k) for k in ("kernel", "frac", "avg_launch_ms")}, "alone", (r.get("one_frame_at_a_time") or {}))
 for k, c in (d.get("cases") or {}).items():
