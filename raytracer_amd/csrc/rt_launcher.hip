@@ -817,10 +817,14 @@ int wavefrontFrame(rt_ctx *c, const rt_trace_params *params, int n, const rt_rec
     wp.rowChunkDiv = c->tuneRowChunkDiv;
     wp.extendCacheNodes = c->tuneCacheNodes;
     wp.extendRaysPerWave = c->tuneRaysPerWave;
-    // rays per wave of a sparse stage: spread thinly (fill 2) a frame on its own finishes sooner; with frames in flight
-    // the idle lanes of thin waves are issue slots the other frames could use, and fuller waves (fill 1) win
-    // (metric frame 0.92 -> 0.89 ms with four in flight, 1.67 -> 1.73 ms alone).  RT_WF_FILL overrides.
-    wp.extendFill = c->tuneFill > 0 ? c->tuneFill : (beforeCommit ? 1 : 2);
+    // rays per wave of a sparse stage: spread thinly (fill 2) a frame on its own finishes sooner (1.67 against 1.73 ms).
+    // With frames in flight the idle lanes of thin waves are issue slots the other frames could use: in round 2 fuller
+    // waves (fill 1) won (0.92 -> 0.89 ms).  Since the filter of a frame no longer holds up the next frame's commit
+    // (rt_filter) that holds for long runs of frames only — 120 frames: fill 1 / 2 = 0.781 / 0.794 ms with four lanes,
+    // 0.726 / 0.775 with eight — while bursts of 20 between two syncs, the shape the metric is timed in, take 0.799 / 0.771 ms
+    // per frame (eight alternating runs each, three boxes): four lanes get the thin spread, more lanes (a caller's choice
+    // for long runs) the full waves.  RT_WF_FILL overrides.
+    wp.extendFill = c->tuneFill > 0 ? c->tuneFill : ((beforeCommit && lanesInUse(c) > 4) ? 1 : 2);
     wp.extendMinRays = c->tuneMinRays;
     // beyond the L2s every walk step is a trip to memory: stop the walk phase early at any wave width;
     // L2-resident scenes: only while the wave is (nearly) full

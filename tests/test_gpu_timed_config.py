@@ -223,7 +223,7 @@ def bench_shape(scene, frames, want_dense, in_flight_setting=0):
                 assert s["pipelined"] == 0 and s["frames_in_flight"] == 1 and s["fill"] == 2 and s["extend_blocks_per_cu"] == 4, s
                 assert s["dense"] == (1 if want_dense else 0) and (want_dense or s["rows_stage_mask"] != 0), s
             else:       # frames in flight: two blocks per CU and no row mode (three blocks on dense frames)
-                assert s["pipelined"] == 1 and s["frames_in_flight"] == 4 and s["fill"] == 1 and s["rows_stage_mask"] == 0, s
+                assert s["pipelined"] == 1 and s["frames_in_flight"] == 4 and s["fill"] == 2 and s["rows_stage_mask"] == 0, s
                 assert (s["dense"], s["extend_blocks_per_cu"]) == ((1, 3) if want_dense else (0, 2)), s
         assert sorted({s["lane"] for s in schedules}) == ([0] if alone else list(range(min(4, frames))))
         if alone and not want_dense:
