@@ -1551,6 +1551,10 @@ int rt_counters_reset(rt_ctx *c) {
     if (rc) return rc;
     if ((rc = rtJoinLanes(c))) return rc;
     HIP_TRY(c, hipMemsetAsync(c->counters.p, 0, sizeof(RtCountersDev) * RT_COUNTER_SHARDS, c->stream));
+    // The next frame in flight starts on ANOTHER lane's stream and only its last kernel waits for this one: its first
+    // kernels count (the primary rays that stop at the root box) and would race with the memset — seen as a frame's
+    // ray count short by exactly those rays when four processes shared one GPU (scripts/rehearse_multi_gpu.sh 4).
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
 

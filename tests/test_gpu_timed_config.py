@@ -329,3 +329,38 @@ def test_filter_on_the_lane_is_not_disturbed_by_the_frames_behind_it(scene, tail
     if got_levels is not None:
         assert np.array_equal(got_levels, want_levels)
     assert np.array_equal(got_color.view(np.uint32), want_color.view(np.uint32))
+
+
+def test_counter_reset_is_ordered_before_the_next_frame_in_flight():
+    """rt_counters_reset while frames are in flight: the reset is queued behind the frames already there, but the next
+    frame starts on another lane and only its LAST kernel waits for what was queued before — its first kernel counts
+    (pixel-samples, the primary rays that stop at the root box) and must not be overtaken by the reset.  (Found when four
+    processes shared one GPU: a frame's ray count came out short by exactly the rays of the classify kernel.)"""
+    W, H, spp, mb = 1920, 1080, 4, 5
+    wl = workloads.Workload("room", W, H)
+    ctx = make_ctx()
+    try:
+        ctx.upload_scene(wl.buffers)
+        ctx.resize(W, H)
+
+        def trace(k):
+            ctx.trace_samples(wl.rays, wl.eye, spp=spp, frame0=spp * k, max_bounces=mb, flags=0, num_emitters=wl.num_emitters)
+
+        settle = 0
+        while ctx.walk_stop() == 0 and settle < 8:
+            trace(0)
+            settle += 1
+        ctx.sync()
+        ctx.reset_counters()
+        trace(0)
+        want = ctx.counters()                       # one frame, nothing else on the GPU
+        for k in range(3):                          # ~0.1 s of work on the lanes ...
+            trace(k)
+        ctx.reset_counters()                        # ... behind which the reset is queued
+        trace(0)
+        got = ctx.counters()
+    finally:
+        ctx.close()
+    assert want.paths == W * H * spp
+    for name in ("paths", "rays", "node_visits", "tri_tests", "primary_node_visits", "shaded_hits"):
+        assert getattr(got, name) == getattr(want, name), (name, getattr(got, name), getattr(want, name))
