@@ -189,6 +189,9 @@ inline int ensure(rt_ctx *c, DevBuf &b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b.p && b.bytes >= bytes) return RT_OK;
     if (b.p) {
+        // (growing a buffer that kernels in flight on any lane may still use: hipFree waits for the device as the
+        // runtime implements it today; said explicitly here so that it does not depend on that)
+        HIP_TRY(c, hipDeviceSynchronize());
         HIP_TRY(c, hipFree(b.p));
         b.p = nullptr;
         b.bytes = 0;
