@@ -127,9 +127,56 @@ __device__ __forceinline__ f3 around(f3 v, f3 z) { // random.glsl:86-90
     f3 t = ortho(z), b = cross(z, t);
     return (t * v.x + b * v.y) + z * v.z;
 }
+// pow / sin / cos: the functions whose precision GLSL leaves to the implementation.  The reference's pinned platform
+// (llvmpipe) evaluates them with polynomials that are "within about 1 ulp of libm, not bit-identical" (SURVEY Appendix
+// B), so nothing downstream of them is bit-pinned: radiance is compared within tests/util.py's tolerance.  libm's forms
+// are long on this GPU (sinf / cosf carry a Payne-Hanek reduction for arguments that never occur here, powf is ~150
+// instructions) and the logic kernel is a tenth of a dense frame's VALU time, so (round 3):
+//   pow(x, y) = v_exp_f32(y * v_log_f32(x)) for x >= 0 (all call sites: random numbers in [0, 1) and max(0, dot));
+//               y == 0 -> 1 as powf, x == 0 -> 0;
+//   sin, cos of p = 2 pi rp (random.glsl:94-95): one shared quadrant reduction + two short polynomials (rtSinCos,
+//               max error 0.8 ulp(1) over all 2^23 values of rp, checked exhaustively on the CPU).  The hardware's
+//               v_sin_f32 / v_cos_f32 were tried first: ~1e-6 off, which on config #5 (50 M small triangles) moved
+//               1.36 % of the hit pixels' secondary rays onto a neighbouring triangle (test limit 1 %; 0.27 % with
+//               libm, 0.36 % with rtSinCos).
+// Logic kernel: 4 480 -> 2 904 VALU instructions.  Measured on MI355X, A/B in one GPU call: room.obj 31.3 -> 30.2 ms per
+// frame; outliers beyond the radiance tolerance against the oracle 1.1e-5 -> 1.1e-5 of the pixels (limit 2e-3), RMSE /
+// mean 8.8e-5 -> 9.4e-5.  Divisions and square roots stay correctly rounded: llvmpipe's are.
+// -DRT_LIBM_TRANSCENDENTALS builds the libm forms (rounds 1-2).
+#ifndef RT_LIBM_TRANSCENDENTALS
+__device__ __forceinline__ float rtPow(float x, float y) {
+    return y == 0.0f ? 1.0f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
+// sin and cos of p in [0, 2 pi]: quadrant j = rint(p * 2/pi) <= 4, r = p - j * pi/2 with pi/2 in three pieces (the first
+// two have few enough bits that j * piece is exact), then the minimax polynomials of the Cephes single-precision
+// routines on [-pi/4, pi/4]; explicit fused operations (this file is built with contraction off).
+__device__ __forceinline__ void rtSinCos(float p, float &sn, float &cs) {
+    const float j = rintf(p * 0.636619772f);
+    float r = fmaf(-j, 1.5703125f, p);
+    r = fmaf(-j, 4.837512969970703125e-4f, r);
+    r = fmaf(-j, 7.54978995489188216e-8f, r);
+    const float z = r * r;
+    const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                          fmaf(-0.5f, z, 1.0f));
+    const int q = (int)j;
+    const float a = (q & 1) ? cp : sp, b = (q & 1) ? sp : cp;
+    sn = (q & 2) ? -a : a;
+    cs = ((q + 1) & 2) ? -b : b;
+}
+#else
+__device__ __forceinline__ float rtPow(float x, float y) { return powf(x, y); }
+#endif
 __device__ __forceinline__ f3 isotropic(float rp, float c) { // random.glsl:92-96
-    float p = TWO_PI_F * rp, s = sqrtf(1.0f - c * c);
+    float s = sqrtf(1.0f - c * c);
+#ifndef RT_LIBM_TRANSCENDENTALS
+    float sn, cs;
+    rtSinCos(TWO_PI_F * rp, sn, cs);
+    return F3(cs * s, sn * s, c);
+#else
+    float p = TWO_PI_F * rp;
     return F3(cosf(p) * s, sinf(p) * s, c);
+#endif
 }
 // random.glsl:98-101 (its ONE_OVER_2PI expands to 1.0/(2 * PI))
 __device__ __forceinline__ f3 randomHemispherePoint(f3 n, float rx, float ry, float &pdf) {
@@ -147,12 +194,12 @@ __device__ __forceinline__ float randomCosineWeightedHemispherePDF(f3 n, f3 v) {
 }
 __device__ __forceinline__ f3 randomPhongWeightedHemispherePoint(f3 r, float a, float rx, float ry, float &pdf) {
     float ai = 1.0f / (a + 1.0f); // random.glsl:131-135
-    pdf = (a + 1.0f) * powf(ry, a * ai) / TWO_PI_F;
-    return around(isotropic(rx, powf(ry, ai)), r);
+    pdf = (a + 1.0f) * rtPow(ry, a * ai) / TWO_PI_F;
+    return around(isotropic(rx, rtPow(ry, ai)), r);
 }
 __device__ __forceinline__ float randomPhongWeightedHemispherePDF(f3 r, float a, f3 v) { // random.glsl:137-142
     if (dot(r, v) < 0.0f) return 0.0f;
-    return (a + 1.0f) * powf(fmaxf(0.0f, dot(r, v)), a) / TWO_PI_F;
+    return (a + 1.0f) * rtPow(fmaxf(0.0f, dot(r, v)), a) / TWO_PI_F;
 }
 
 struct LightTri { // the fields of an emitter record that sampling and visible() consume
@@ -756,7 +803,7 @@ __device__ __forceinline__ float PowerHeuristic(int nf, float fpdf, int ng, floa
 __device__ __forceinline__ f3 brdfSpecular(float Ns, f3 i, f3 o, f3 n) {
     f3 r = reflect(-i, n);
     if (dot(r, o) < 0.0f) return F3(0, 0, 0);
-    float s = powf(fmaxf(0.0f, dot(r, o)), Ns) * (Ns + 2.0f) * ONE_OVER_2PI_T3;
+    float s = rtPow(fmaxf(0.0f, dot(r, o)), Ns) * (Ns + 2.0f) * ONE_OVER_2PI_T3;
     return F3(s, s, s);
 }
 __device__ __forceinline__ f3 brdfDiffuse(f3 Kd) { return Kd * ONE_OVER_PI_T3; }
