@@ -370,6 +370,13 @@ int rt_profile(rt_ctx *ctx, int enable);             /* HIP-event timing of ever
 int rt_timings_read(rt_ctx *ctx, rt_timings *out, int reset); /* blocking */
 int rt_sync(rt_ctx *ctx);
 
+/* Self-test of the shading code's pow / sin / cos (no counterpart in the reference; GLSL leaves the precision of
+ * random.glsl:94-95,133-141 and trace3.cs:335 to the implementation, and the library evaluates them with short forms of
+ * its own: DESIGN.md 4.2).  For i < n (n <= 2^24): in[3i] = rp in [0, 1), in[3i+1] = x >= 0, in[3i+2] = y;
+ * out[3i] = sin(2 pi rp), out[3i+1] = cos(2 pi rp), out[3i+2] = pow(x, y), each as the trace kernels compute it.
+ * Host pointers; blocking; allocates and frees its own device memory. */
+int rt_shading_math(rt_ctx *ctx, int n, const float *in, float *out);
+
 /* Launch geometry of the trace kernel, as ComputeShader::workGroupSize reports it. */
 void rt_work_group_size(int kernel, int out_xyz[3]);
 const char *rt_version(void);

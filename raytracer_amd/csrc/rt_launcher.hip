@@ -18,6 +18,7 @@
 #include "trace3_rl.h"
 #include "wavefront.h"
 
+hipError_t rtLaunchShadingMath(const float *in, float *out, int n, hipStream_t stream);
 hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace_params &p, const rt_rect &tile,
                           int xcdRemap, RtCountersDev *counters, hipStream_t stream, const RtBlueTablesHost *blueHost);
 // Called by the wavefront launcher between its kernels when profiling is on.
@@ -1422,6 +1423,27 @@ int rt_flat_cells(rt_ctx *c, int which, uint8_t *flags, size_t nbytes) {
     if ((rc = rtJoinLanes(c))) return rc;
     HIP_TRY(c, hipMemcpyAsync(flags, src, need, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_shading_math(rt_ctx *c, int n, const float *in, float *out) {
+    if (!c || !in || !out) return RT_EINVAL;
+    if (n < 0 || n > (1 << 24)) return fail(c, RT_EINVAL, "rt_shading_math: n must be 0 .. 2^24");
+    if (n == 0) return RT_OK;
+    int rc = bind(c);
+    if (rc) return rc;
+    if ((rc = rtJoinLanes(c))) return rc;
+    const size_t bytes = (size_t)3 * n * sizeof(float);
+    float *din = nullptr, *dout = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&din, bytes));
+    hipError_t e = hipMalloc((void **)&dout, bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = rtLaunchShadingMath(din, dout, n, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(din);
+    if (dout) (void)hipFree(dout);
+    if (e != hipSuccess) return fail(c, RT_EHIP, std::string("rt_shading_math: ") + hipGetErrorString(e));
     return RT_OK;
 }
 

@@ -135,7 +135,7 @@ __device__ __forceinline__ f3 around(f3 v, f3 z) { // random.glsl:86-90
 //   pow(x, y) = v_exp_f32(y * v_log_f32(x)) for x >= 0 (all call sites: random numbers in [0, 1) and max(0, dot));
 //               y == 0 -> 1 as powf, x == 0 -> 0;
 //   sin, cos of p = 2 pi rp (random.glsl:94-95): one shared quadrant reduction + two short polynomials (rtSinCos,
-//               max error 0.8 ulp(1) over all 2^23 values of rp, checked exhaustively on the CPU).  The hardware's
+//               max error 0.8 ulp(1) over all 2^23 values of rp: tests/test_gpu_shading_math.py).  The hardware's
 //               v_sin_f32 / v_cos_f32 were tried first: ~1e-6 off, which on config #5 (50 M small triangles) moved
 //               1.36 % of the hit pixels' secondary rays onto a neighbouring triangle (test limit 1 %; 0.27 % with
 //               libm, 0.36 % with rtSinCos).

@@ -166,3 +166,19 @@ hipError_t rtLaunchTrace3(const RtScene &sc, const RtImages &img, const rt_trace
                        tilesY, xcdRemap, counters, blue);
     return hipGetLastError();
 }
+
+// rt_shading_math (include/rt_launcher.h): the library's own pow / sin / cos (trace3_device.h: rtPow, isotropic) on
+// caller-supplied values, so that a test can bound their error against double precision.
+__global__ void rt_shading_math_kernel(const float *__restrict__ in, float *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 d = isotropic(in[3 * i], 0.0f); // c = 0: s = 1, d = (cos(2 pi rp), sin(2 pi rp), 0)
+    out[3 * i] = d.y;
+    out[3 * i + 1] = d.x;
+    out[3 * i + 2] = rtPow(in[3 * i + 1], in[3 * i + 2]);
+}
+hipError_t rtLaunchShadingMath(const float *in, float *out, int n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rt_shading_math_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, out, n);
+    return hipGetLastError();
+}

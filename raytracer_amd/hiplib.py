@@ -82,7 +82,7 @@ EXPORTS = ["rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_uplo
            "rt_clear", "rt_trace", "rt_trace_batch", "rt_trace_batch_static", "rt_static_max_paths", "rt_filter", "rt_filter_halo", "rt_tonemap", "rt_readback",
            "rt_readback_rect_device", "rt_write_rect_device", "rt_write_rect_device_async", "rt_write_image", "rt_image_pixel_bytes",
            "rt_counters_read", "rt_counters_reset", "rt_profile", "rt_timings_read", "rt_sync",
-           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_gather_tiles", "rt_walk_stop", "rt_last_schedule", "rt_filtered_lane", "rt_set_frames_in_flight", "rt_frames_in_flight", "rt_flat_cells",
+           "rt_comm_unique_id", "rt_comm_init", "rt_comm_destroy", "rt_gather_tiles", "rt_walk_stop", "rt_last_schedule", "rt_filtered_lane", "rt_set_frames_in_flight", "rt_frames_in_flight", "rt_flat_cells", "rt_shading_math",
            "rt_work_group_size", "rt_version"]
 
 _lib = None
@@ -109,6 +109,7 @@ def lib():
         L.rt_download.argtypes = [vp, i32, vp, sz]
         L.rt_resize.argtypes = [vp, i32, i32]
         L.rt_clear.argtypes = [vp]
+        L.rt_shading_math.argtypes = [vp, i32, vp, vp]
         L.rt_trace.argtypes = [vp, ctypes.POINTER(TraceParams), rp]
         L.rt_trace_batch.argtypes = [vp, ctypes.POINTER(TraceParams), i32, rp]
         L.rt_trace_batch_static.argtypes = [vp, ctypes.POINTER(TraceParams), i32, rp]
@@ -347,6 +348,14 @@ class Context:
         """n > 1 (default 4): successive frames rotate over n internal streams; 1: one frame at a time; 0: the launcher's
         own choice again (4, or 3 for a scene beyond the L2 caches)."""
         self._check(lib().rt_set_frames_in_flight(self._h, int(n)), "rt_set_frames_in_flight")
+
+    def shading_math(self, rp, x, y):
+        """rt_shading_math: (sin(2 pi rp), cos(2 pi rp), pow(x, y)) as the trace kernels compute them, three float32 arrays."""
+        a = np.ascontiguousarray(np.stack([np.asarray(rp, np.float32), np.asarray(x, np.float32), np.asarray(y, np.float32)], axis=1))
+        out = np.empty_like(a)
+        self._check(lib().rt_shading_math(self._h, a.shape[0], a.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p)),
+                    "rt_shading_math")
+        return out[:, 0].copy(), out[:, 1].copy(), out[:, 2].copy()
 
     def flat_cells(self, which=0):
         """rt_flat_cells: the flags of the 16 x 16 cells recorded as flat, [cellsY, cellsX] (0: by the last wavefront
